@@ -1,0 +1,120 @@
+/*
+ * hj_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement of the reference's hash-join build+probe hot path
+ * (anilshanbhag/HTM-HashJoin).  It exists only so that tests/, bench.py's
+ * cpu_baseline leg and __graft_entry__.smoke() can check the HIP engine
+ * against the reference's semantics.  Nothing under htm-hashjoin_amd/ may
+ * include, link or call it.
+ *
+ * Parity status: PINNED.
+ *   - nocc/atomic path: pinned by the reference's own committed run logs
+ *     (experiments/new_backup/probe_log*, AtomicsVsHTMVsNoCC_log*,
+ *     experiments/overflow_log1) -- see tests/golden/reference_logs.json --
+ *     and by SURVEY.md Appendix B/C values.  The reference's main.cpp path
+ *     itself is NOT buildable here (it needs Intel TBB headers, which this
+ *     image lacks), so no oracle/_ref binary exists for it.
+ *   - PRJ path: pinned by oracle/_ref/mchashjoins, compiled from the
+ *     reference's mc/src/ sources where they lie (oracle/Makefile), and by
+ *     experiments/new_backup/motivation_log1:8 (Results = 549688705024).
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * the reference checkout).
+ */
+#ifndef HJ_ORACLE_H
+#define HJ_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- DataGen (include/DataGen.hpp:26-122) -------------------------------- */
+
+/* Fills out[0..n) exactly as generate_data(dist, n, distinct, window) does,
+ * calling libc srand(0)/rand() in the same order.  dist is one of
+ * "uniform","random","sorted","shuffle","local_shuffle".
+ * Returns 0, or -1 for an unknown distribution (the reference exits(1)). */
+int orc_generate_data(const char *dist, uint64_t n, uint64_t distinct,
+                      int window, uint64_t *out);
+
+/* Zipf probe-side generator (extension; the reference's DataGen "zipf" branch
+ * is an empty stub, DataGen.hpp:72-77).  Follows mc/src/genzipf.c:60-158:
+ * random alphabet permutation + cumulative LUT + binary search, driven by
+ * libc rand() after srand(seed). */
+int orc_generate_zipf(uint64_t n, uint32_t alphabet, double theta,
+                      unsigned seed, uint64_t *out);
+
+/* ---- nocc / atomic build + probe (sequential order) ---------------------- */
+
+typedef struct {
+    uint64_t rSize, sSize, tableSize;
+    uint64_t conflicts;     /* tuples that exhausted the probe budget         */
+    uint64_t totalMatches;  /* probe matches (NoCCHashBuild.hpp:66-80)        */
+    uint64_t inputSum;      /* sum of R                 (:85-92)              */
+    uint64_t tableSumHalf;  /* sum output[0..rSize)     (:94-101, nocc quirk) */
+    uint64_t tableSumFull;  /* sum output[0..tableSize) (Atomic :100-107)     */
+    uint64_t conflictSum;   /* sum of dropped keys      (:103-113)            */
+    uint64_t outputSumNocc;   /* tableSumHalf + conflictSum  (:145)           */
+    uint64_t outputSumAtomic; /* tableSumFull + conflictSum  (intended value
+                                 of AtomicHashBuild.hpp:151; the reference's
+                                 own conflictSum indexes out of bounds when
+                                 conflicts>0, :111-114, so only the
+                                 conflicts==0 value is pinned)               */
+    double   build_us, probe_us;
+} orc_result;
+
+/* Sequential-order restatement of NoCCHashBuild.hpp:37-81 (== AtomicHashBuild
+ * .hpp:37-86 when run by one thread: the CAS never fails).  tableSize =
+ * 2*rSize, identity hash key&(tableSize-1), linear probing with probeLength
+ * budget, dropped tuples counted as conflicts.  S may be NULL (build only).
+ * If table_out != NULL it receives the tableSize final slots (0 = empty).
+ * The table is allocated with 4 zero slots of slack so that the reference's
+ * unmasked probe walk (curSlot++ without & tableMask, :74-75) reads "empty"
+ * where the reference would read out of bounds. */
+int orc_build_probe_seq(const uint64_t *R, uint64_t rSize,
+                        const uint64_t *S, uint64_t sSize,
+                        uint32_t probeLength, orc_result *res,
+                        uint64_t *table_out);
+
+/* Threaded port used ONLY as the timed CPU baseline ("port"): numPartitions
+ * contiguous chunks pulled by nthreads pthreads, exactly the chunking of
+ * parallel_for(blocked_range(0,rSize,rSize/numPartitions)).  atomic=0 -> the
+ * racy plain-store loop (nocc), atomic=1 -> relaxed load + CAS incl. the
+ * "failed CAS costs budget without advancing" quirk (AtomicHashBuild.hpp:
+ * 50-54).  On duplicate keys its counts are order dependent, as the
+ * reference's are. */
+int orc_build_probe_mt(const uint64_t *R, uint64_t rSize,
+                       const uint64_t *S, uint64_t sSize,
+                       uint32_t probeLength, uint32_t numPartitions,
+                       int nthreads, int atomic, orc_result *res);
+
+/* ---- PRJ (mc/src/parallel_radix_join.c) ---------------------------------- */
+
+typedef struct {
+    uint64_t matches;    /* join cardinality: the probe loop the fork commented
+                            out (parallel_radix_join.c:259-276), restored     */
+    uint64_t checksum;   /* sum of bucket idx over all R tuples (:249-256):
+                            what the fork's PRO prints as "Results"           */
+    uint64_t partitions; /* non-empty R partitions joined                     */
+    double   part_us, join_us;
+} orc_prj_result;
+
+/* Two-pass radix partition of R and S on the low radix_bits key bits
+ * (pass 1: bits [0, radix_bits/2), pass 2: the rest -- prj_thread :814-816,
+ * radix_cluster :402-440) followed by bucket_chaining_join (:231-283) per
+ * partition pair.  S may be NULL (then matches = 0, as in the fork). */
+int orc_prj_join(const uint64_t *R, uint64_t nR, const uint64_t *S,
+                 uint64_t nS, uint32_t radix_bits, orc_prj_result *res);
+
+/* Reference-free cross-check: exact join cardinality sum_k cntR(k)*cntS(k)
+ * by sorting both sides. */
+uint64_t orc_true_cardinality(const uint64_t *R, uint64_t nR,
+                              const uint64_t *S, uint64_t nS);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
