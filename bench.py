@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- hash-join build+probe throughput on MI355X (the BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--log2n 30] [--dist uniform]
+
+One "step" = one pass of the hot path over one batch: clear table -> build(R) -> probe(S)
+with R and S already resident in HBM (DataGen inputs, generated on the host and copied
+in before the timed region). N=1 workload: |R| = |S| = 2^30 uint32-key tuples, `uniform`
+(BASELINE.json metric; configs[1]'s operator at the metric's size). For N > 1 (launched
+with torch.distributed.run, one rank per GPU) every rank holds its own 2^log2n-tuple
+shard of R and S ("weak" scaling); tuples are exchanged by key radix with one all-to-all
+per relation over RCCL and joined locally (htm_hashjoin_amd/sharded.py).
+
+Rank 0 prints ONE JSON line. `value` = (|R|+|S|) summed over all ranks / max-over-ranks
+time, in Mtuples/s. Extra objects: `roofline` (dominant kernel, HIP-event timed on the
+launch stream), `cpu_baseline` (the oracle's threaded port on a bounded sample, rank 0,
+N=1 only), `other_workloads` (local_shuffle and PRJ measured in the same process).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log2n", type=int, default=30, help="per-GPU |R| = |S| = 2^log2n")
+    ap.add_argument("--dist", default="uniform")
+    ap.add_argument("--shuffle-range", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other_workloads legs")
+    ap.add_argument("--cpu-sample-log2n", type=int, default=27)
+    return ap.parse_args()
+
+
+def to_device(np_u64, torch, dev):
+    t = torch.from_numpy(np_u64.view("int64"))
+    return t.to(dev, non_blocking=False)
+
+
+def time_steps(torch, dist_mod, world, fn, steps, warmup):
+    """W untimed + exactly K timed steps between barrier+synchronize; returns max-over-ranks seconds."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist_mod.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist_mod.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def oa_leg(torch, hj, ctx, n, dist, window, steps, warmup, S_dev=None):
+    """Open-addressing build+probe on one GPU. Returns (result dict, S_dev)."""
+    R = hj.generate_data(dist, n, n, window)
+    R_dev = to_device(R, torch, "cuda")
+    del R
+    if S_dev is None:
+        S_dev = torch.arange(1, n + 1, dtype=torch.int64, device="cuda")   # generate_data("sorted"), main.cpp:93
+    ctx.reserve("atomic", n, n)
+    kernel_us = {"clear_us": [], "build_us": [], "probe_us": []}
+
+    def step():
+        ctx.build(R_dev.data_ptr(), n)
+        ctx.probe(S_dev.data_ptr(), n)
+
+    dt = time_steps(torch, None, 1, step, steps, warmup)
+    # per-kernel device times of the same launches, from HIP events on the launch stream
+    for _ in range(min(steps, 5)):
+        step()
+        r = ctx.fetch()
+        for k in kernel_us:
+            kernel_us[k].append(r[k])
+    ctx.checksums()
+    res = ctx.fetch()
+    avg = {k: sum(v) / len(v) for k, v in kernel_us.items()}
+    out = {
+        "dist": dist, "shuffleRange": window, "rSize": n, "sSize": n,
+        "ms_per_step": dt / steps * 1e3,
+        "mtuples_per_s": 2 * n / (dt / steps) / 1e6,
+        "kernel_us": avg,
+        "conflicts": res["conflicts"], "totalMatches": res["totalMatches"], "inputSum": res["inputSum"],
+        "checks": {
+            "matches_plus_conflicts_eq_rSize": res["totalMatches"] + res["conflicts"] == n,
+            "tableSum_plus_conflictSum_eq_inputSum": res["tableSumFull"] + res["conflictSum"] == res["inputSum"],
+        },
+    }
+    del R_dev
+    return out, S_dev
+
+
+def prj_leg(torch, hj, ctx, n, dist, window, steps, warmup, S_dev):
+    R = hj.generate_data(dist, n, n, window)
+    R_dev = to_device(R, torch, "cuda")
+    del R
+    ctx.reserve("prj", n, n)
+
+    def step():
+        ctx.prj_join(R_dev.data_ptr(), n, S_dev.data_ptr(), n)
+
+    dt = time_steps(torch, None, 1, step, steps, warmup)
+    step()
+    res = ctx.fetch()
+    return {
+        "algo": "prj", "dist": dist, "shuffleRange": window, "rSize": n, "sSize": n,
+        "radixBits": res["radixBits"], "ms_per_step": dt / steps * 1e3,
+        "mtuples_per_s": 2 * n / (dt / steps) / 1e6,
+        "partition_us": res["partition_us"], "join_us": res["join_us"],
+        "totalMatches": res["totalMatches"],
+        "hbm_frac_of_32B_per_tuple": 32.0 * 2 * n / (dt / steps) / 1e9 / HBM_PEAK_GBPS,
+        "checks": {"matches_eq_n": res["totalMatches"] == n},
+    }
+
+
+def cpu_baseline(hj, log2n, dist, window):
+    """The oracle's threaded port (oracle/hj_oracle.c: orc_build_probe_mt) on the host cores:
+    same distribution at 2^log2n tuples (the reference's own experiment size), 64 chunks as
+    in parallel_for(blocked_range(0, rSize, rSize/64)), min(64, cores) threads."""
+    from oracle import oracle   # checker/baseline only
+    n = 1 << log2n
+    cores = os.cpu_count() or 1
+    threads = min(64, cores)
+    R = hj.generate_data(dist, n, n, window)
+    S = hj.generate_data("sorted", n)
+    best = None
+    for _ in range(3):
+        r = oracle.build_probe_mt(R, S, 4, 64, threads, atomic=True)
+        us = r["build_us"] + r["probe_us"]
+        best = us if best is None else min(best, us)
+    rn = oracle.build_probe_mt(R, S, 4, 64, threads, atomic=False)
+    return {
+        "value": 2 * n / best, "unit": "Mtuples/s", "cores": threads, "kind": "port",
+        "sample": f"atomic (CAS) build+probe, {dist} W={window}, |R|=|S|=2^{log2n}, best of 3; "
+                  f"nocc (racy store) same input: {2 * n / (rn['build_us'] + rn['probe_us']):.0f} Mtuples/s",
+    }
+
+
+def main():
+    a = parse()
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    import htm_hashjoin_amd as hj
+
+    n = 1 << a.log2n
+    if world > 1:
+        import torch.distributed as dist_mod
+        from htm_hashjoin_amd import sharded
+        dist_mod.init_process_group("nccl")
+        line = sharded.bench_sharded(a, torch, dist_mod, hj, rank, world, local_rank)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        dist_mod.destroy_process_group()
+        return
+
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = hj.HashJoinContext(local_rank, stream=stream)
+    main_leg, S_dev = oa_leg(torch, hj, ctx, n, a.dist, a.shuffle_range, a.steps, a.warmup)
+
+    # roofline of the dominant kernel (the build): algorithmic bytes = 16 B per R tuple
+    # (8 read + 8 slot write), duration = HIP-event time of that launch
+    ku = main_leg["kernel_us"]
+    dominant = max(("build_us", "probe_us", "clear_us"), key=lambda k: ku[k])
+    alg_bytes = {"build_us": 16.0 * n, "probe_us": 16.0 * n, "clear_us": 16.0 * n}[dominant]
+    achieved = alg_bytes / (ku[dominant] * 1e-6) / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        traffic = json.load(open(pmc)).get({"build_us": "k_build_atomic_min", "probe_us": "k_probe",
+                                            "clear_us": "k_fill_empty"}[dominant])
+    roofline = {"bound": "hbm", "kernel": {"build_us": "k_build_atomic_min", "probe_us": "k_probe",
+                                           "clear_us": "k_fill_empty"}[dominant],
+                "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": traffic,
+                "per_kernel_GBps": {k: 16.0 * n / (ku[k] * 1e-6) / 1e9 for k in ku},
+                "whole_step_frac": (48.0 * n) / (main_leg["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+
+    extra = {}
+    if not a.no_extra:
+        k2 = max(2, a.steps // 2)
+        extra["oa_local_shuffle_1024"], _ = oa_leg(torch, hj, ctx, n, "local_shuffle", 1024, k2, 1, S_dev)
+        ctx2 = hj.HashJoinContext(local_rank, stream=stream)
+        extra["prj_local_shuffle_1024"] = prj_leg(torch, hj, ctx2, n, "local_shuffle", 1024, k2, 1, S_dev)
+        ctx2.close()
+    ctx.close()
+    del S_dev
+    torch.cuda.empty_cache()
+
+    cpu = None
+    if not a.no_cpu_baseline:
+        cpu = cpu_baseline(hj, min(a.cpu_sample_log2n, a.log2n), a.dist, a.shuffle_range)
+
+    line = {
+        "metric": "Mtuples/sec build+probe, |R|=|S|=1B uint32, uniform vs local_shuffle",
+        "value": main_leg["mtuples_per_s"], "unit": "Mtuples/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": main_leg["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64 tuples (u32 key), integer", "data": "synthetic (DataGen restatement, srand(0) glibc stream)",
+        "config": {"workload": f"open-addressing build+probe (atomic), |R|=|S|=2^{a.log2n}, dataDistr={a.dist} "
+                               f"W={a.shuffle_range}, S=sorted, probeLength=4, tableSize=2|R|; "
+                               "step = table clear + build + probe, inputs resident in HBM",
+                   "algo": "atomic", "rSize": n, "sSize": n, "dataDistr": a.dist, "shuffleRange": a.shuffle_range},
+        "result": {k: main_leg[k] for k in ("conflicts", "totalMatches", "inputSum", "checks")},
+        "roofline": roofline, "cpu_baseline": cpu, "other_workloads": extra,
+    }
+    print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

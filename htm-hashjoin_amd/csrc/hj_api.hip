@@ -1,0 +1,473 @@
+// hj_api.hip -- implementation of the C ABI in include/htm_hashjoin.h.
+// Host-side glue only: argument checks, device memory, stream order, HIP-event
+// timing. All arithmetic on tuples happens in hj_kernels.hip / hj_prj.hip.
+// There is no CPU fallback in here: every operator needs a gfx950 device.
+
+#include "../../include/htm_hashjoin.h"
+#include "hj_device.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+using namespace hj;
+
+namespace {
+enum Ev { EV_CLEAR0, EV_BUILD0, EV_BUILD1, EV_PROBE0, EV_PROBE1, EV_PRJ0, EV_PRJ_PART, EV_PRJ1, EV_COUNT };
+}
+
+struct hj_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    hj_params params{};
+    // open-addressing table
+    uint64_t* table = nullptr;
+    uint64_t tableCapSlots = 0;   // allocated slots incl. slack
+    uint64_t tableSize = 0;       // live table (2*rSize) of the last build
+    uint64_t tableBase = 0;       // first global slot held (0 unless a slice)
+    uint64_t rSize = 0, sSize = 0;
+    bool built = false;
+    // counters
+    Counters* dCtr = nullptr;
+    Counters* hCtr = nullptr;     // pinned
+    // PRJ workspace
+    PrjPlan plan{};
+    uint64_t *tmpA = nullptr, *partR = nullptr, *partS = nullptr;
+    void* work = nullptr;
+    uint64_t capTmp = 0, capPartR = 0, capPartS = 0;
+    size_t capWork = 0;
+    bool prjRan = false;
+    // staging for hj_run
+    uint64_t *stageR = nullptr, *stageS = nullptr;
+    uint64_t capStageR = 0, capStageS = 0;
+    // shard helper scratch
+    unsigned long long* shardCursors = nullptr;
+    // timing
+    hipEvent_t ev[EV_COUNT]{};
+    bool evSet[EV_COUNT]{};
+    double h2d_us = 0;
+    std::string err;
+};
+
+namespace {
+
+int fail(hj_ctx* c, int code, const char* what, hipError_t e = hipSuccess)
+{
+    if (c) {
+        char buf[512];
+        if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+        else snprintf(buf, sizeof buf, "%s", what);
+        c->err = buf;
+    }
+    return code;
+}
+
+#define HJ_HIP(c, call)                                                     \
+    do {                                                                    \
+        hipError_t e_ = (call);                                             \
+        if (e_ != hipSuccess)                                               \
+            return fail((c), e_ == hipErrorOutOfMemory ? HJ_ERR_OOM : HJ_ERR_HIP, #call, e_); \
+    } while (0)
+
+bool is_pow2(uint64_t v) { return v && !(v & (v - 1)); }
+
+uint32_t probe_len(const hj_params& p) { return p.probeLength ? p.probeLength : 4; }
+
+template <typename T>
+int grow(hj_ctx* c, T*& ptr, uint64_t& cap, uint64_t need)
+{
+    if (need <= cap) return HJ_OK;
+    if (ptr) { HJ_HIP(c, hipFree(ptr)); ptr = nullptr; cap = 0; }
+    void* p = nullptr;
+    HJ_HIP(c, hipMalloc(&p, need * sizeof(T)));
+    ptr = static_cast<T*>(p);
+    cap = need;
+    return HJ_OK;
+}
+
+uint32_t auto_radix_bits(uint64_t nR)
+{
+    // >= NUM_RADIX_BITS (prj_params.h:16) and enough that an average R partition
+    // fills at most half of the LDS table; two passes of <= 8 bits
+    uint32_t bits = 14;
+    while (bits < 16 && (nR >> bits) > 16384) ++bits;
+    return bits;
+}
+
+int record(hj_ctx* c, Ev e)
+{
+    HJ_HIP(c, hipEventRecord(c->ev[e], c->stream));
+    c->evSet[e] = true;
+    return HJ_OK;
+}
+
+double elapsed_us(hj_ctx* c, Ev a, Ev b)
+{
+    if (!c->evSet[a] || !c->evSet[b]) return 0.0;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->ev[a], c->ev[b]) != hipSuccess) return 0.0;
+    return (double)ms * 1000.0;
+}
+
+int create_common(int device, void* stream, bool own, hj_ctx** out)
+{
+    if (!out) return HJ_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return HJ_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return HJ_ERR_INVALID;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return HJ_ERR_HIP;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return HJ_ERR_NO_DEVICE;  // kernels are gfx950-only
+    if (hipSetDevice(device) != hipSuccess) return HJ_ERR_HIP;
+    hj_ctx* c = new (std::nothrow) hj_ctx();
+    if (!c) return HJ_ERR_OOM;
+    c->device = device;
+    if (own) {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return HJ_ERR_HIP; }
+        c->ownStream = true;
+    } else {
+        c->stream = static_cast<hipStream_t>(stream);
+    }
+    bool ok = hipMalloc(reinterpret_cast<void**>(&c->dCtr), sizeof(Counters)) == hipSuccess &&
+              hipHostMalloc(reinterpret_cast<void**>(&c->hCtr), sizeof(Counters)) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&c->shardCursors), sizeof(unsigned long long) * 64) == hipSuccess;
+    for (int i = 0; ok && i < EV_COUNT; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+    if (!ok) { hj_destroy(c); return HJ_ERR_HIP; }
+    hipMemset(c->dCtr, 0, sizeof(Counters));
+    memset(c->hCtr, 0, sizeof(Counters));
+    *out = c;
+    return HJ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hj_abi_version(void) { return HJ_ABI_VERSION; }
+
+int hj_device_count(int* count)
+{
+    if (!count) return HJ_ERR_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { *count = 0; return HJ_ERR_NO_DEVICE; }
+    *count = n;
+    return HJ_OK;
+}
+
+int hj_create(int device, hj_ctx** out) { return create_common(device, nullptr, true, out); }
+
+int hj_create_on_stream(int device, void* hip_stream, hj_ctx** out) { return create_common(device, hip_stream, false, out); }
+
+void hj_destroy(hj_ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream || !c->ownStream) hipStreamSynchronize(c->stream);
+    void* frees[] = {c->table, c->dCtr, c->tmpA, c->partR, c->partS, c->work, c->stageR, c->stageS, c->shardCursors};
+    for (void* p : frees) if (p) hipFree(p);
+    if (c->hCtr) hipHostFree(c->hCtr);
+    for (int i = 0; i < EV_COUNT; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
+    if (c->ownStream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* hj_strerror(int status)
+{
+    switch (status) {
+        case HJ_OK: return "ok";
+        case HJ_ERR_INVALID: return "invalid argument";
+        case HJ_ERR_NO_DEVICE: return "no gfx950 HIP device (this library has no CPU fallback)";
+        case HJ_ERR_HIP: return "HIP runtime error";
+        case HJ_ERR_OOM: return "out of device memory";
+        case HJ_ERR_KEY_RANGE: return "tuple outside the DataGen layout (payload bits set or value 0)";
+        case HJ_ERR_UNKNOWN_ALGO: return "unknown algo";
+        case HJ_ERR_STATE: return "call order violated";
+        default: return "unknown status";
+    }
+}
+
+const char* hj_last_error(const hj_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int hj_synchronize(hj_ctx* c)
+{
+    if (!c) return HJ_ERR_INVALID;
+    HJ_HIP(c, hipStreamSynchronize(c->stream));
+    return HJ_OK;
+}
+
+int hj_reserve(hj_ctx* c, const hj_params* params, uint64_t rSize, uint64_t sSize)
+{
+    if (!c || !params) return HJ_ERR_INVALID;
+    if (params->algo > HJ_ALGO_PRJ) return fail(c, HJ_ERR_UNKNOWN_ALGO, "hj_reserve: algo");
+    if (rSize == 0) return fail(c, HJ_ERR_INVALID, "hj_reserve: rSize == 0");
+    HJ_HIP(c, hipSetDevice(c->device));
+    c->params = *params;
+    if (params->algo == HJ_ALGO_PRJ) {
+        if (rSize >= 0xFFFFFFFFull || sSize >= 0xFFFFFFFFull)
+            return fail(c, HJ_ERR_INVALID, "hj_reserve: PRJ sizes must be < 2^32 tuples per device");
+        uint32_t bits = params->radixBits ? params->radixBits : auto_radix_bits(rSize);
+        if (bits < 1 || bits > 16) return fail(c, HJ_ERR_INVALID, "hj_reserve: radixBits must be in [1,16]");
+        c->plan = prj_plan(rSize, sSize, bits);
+        const uint64_t nmax = rSize > sSize ? rSize : sSize;
+        int rc;
+        // +2 tuples: the 16-byte sweeps may touch one tuple past an odd end
+        if ((rc = grow(c, c->tmpA, c->capTmp, nmax + 2))) return rc;
+        if ((rc = grow(c, c->partR, c->capPartR, rSize + 2))) return rc;
+        if (sSize && (rc = grow(c, c->partS, c->capPartS, sSize + 2))) return rc;
+        if (c->plan.workspaceBytes > c->capWork) {
+            if (c->work) { HJ_HIP(c, hipFree(c->work)); c->work = nullptr; c->capWork = 0; }
+            HJ_HIP(c, hipMalloc(&c->work, c->plan.workspaceBytes));
+            c->capWork = c->plan.workspaceBytes;
+        }
+        return HJ_OK;
+    }
+    if (!is_pow2(rSize)) return fail(c, HJ_ERR_INVALID, "hj_reserve: rSize must be a power of two (DataGen.hpp:28, NoCCHashBuild.hpp:36)");
+    if (rSize > (1ull << 31)) return fail(c, HJ_ERR_INVALID, "hj_reserve: rSize > 2^31 per device");
+    return grow(c, c->table, c->tableCapSlots, 2 * rSize + kTableSlack);
+}
+
+int hj_build_dev(hj_ctx* c, const uint64_t* dR, uint64_t rSize, uint64_t idxBase)
+{
+    if (!c || !dR) return HJ_ERR_INVALID;
+    if (c->params.algo == HJ_ALGO_PRJ) return fail(c, HJ_ERR_STATE, "hj_build_dev: context is reserved for PRJ");
+    if (!is_pow2(rSize) || 2 * rSize + kTableSlack > c->tableCapSlots)
+        return fail(c, HJ_ERR_STATE, "hj_build_dev: hj_reserve() not called for this rSize");
+    if (idxBase + rSize > (1ull << 32)) return fail(c, HJ_ERR_INVALID, "hj_build_dev: index range exceeds 32 bits");
+    HJ_HIP(c, hipSetDevice(c->device));
+    c->rSize = rSize; c->sSize = 0; c->tableSize = 2 * rSize; c->tableBase = 0;
+    for (bool& b : c->evSet) b = false;
+    c->prjRan = false;
+    HJ_HIP(c, hipMemsetAsync(c->dCtr, 0, sizeof(Counters), c->stream));
+    int rc;
+    if ((rc = record(c, EV_CLEAR0))) return rc;
+    launch_fill_empty(c->table, c->tableSize + kTableSlack, c->stream);
+    if ((rc = record(c, EV_BUILD0))) return rc;
+    launch_build_atomic_min(dR, rSize, c->table, c->tableSize, probe_len(c->params), idxBase, c->dCtr, c->stream);
+    if ((rc = record(c, EV_BUILD1))) return rc;
+    HJ_HIP(c, hipGetLastError());
+    c->built = true;
+    return HJ_OK;
+}
+
+int hj_build_packed_dev(hj_ctx* c, const uint64_t* dPacked, uint64_t n, uint64_t globalTableSize,
+                        uint64_t slotBase, uint64_t sliceSlots)
+{
+    if (!c || (!dPacked && n)) return HJ_ERR_INVALID;
+    if (!is_pow2(globalTableSize) || slotBase + sliceSlots > globalTableSize || sliceSlots == 0)
+        return fail(c, HJ_ERR_INVALID, "hj_build_packed_dev: bad slice");
+    HJ_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = grow(c, c->table, c->tableCapSlots, sliceSlots + kTableSlack))) return rc;
+    c->rSize = n; c->sSize = 0; c->tableSize = sliceSlots; c->tableBase = slotBase;
+    c->params.algo = HJ_ALGO_ATOMIC;
+    for (bool& b : c->evSet) b = false;
+    c->prjRan = false;
+    HJ_HIP(c, hipMemsetAsync(c->dCtr, 0, sizeof(Counters), c->stream));
+    if ((rc = record(c, EV_CLEAR0))) return rc;
+    launch_fill_empty(c->table, sliceSlots + kTableSlack, c->stream);
+    if ((rc = record(c, EV_BUILD0))) return rc;
+    if (n) launch_build_packed(dPacked, n, c->table, globalTableSize, slotBase, sliceSlots, probe_len(c->params), c->dCtr, c->stream);
+    if ((rc = record(c, EV_BUILD1))) return rc;
+    HJ_HIP(c, hipGetLastError());
+    c->built = true;
+    return HJ_OK;
+}
+
+int hj_probe_dev(hj_ctx* c, const uint64_t* dS, uint64_t sSize)
+{
+    if (!c || (!dS && sSize)) return HJ_ERR_INVALID;
+    if (!c->built) return fail(c, HJ_ERR_STATE, "hj_probe_dev: no table (call hj_build_dev first)");
+    if (c->tableBase != 0) return fail(c, HJ_ERR_STATE, "hj_probe_dev: table is a slice");
+    HJ_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = record(c, EV_PROBE0))) return rc;
+    if (sSize) launch_probe(dS, sSize, c->table, c->tableSize, probe_len(c->params), c->dCtr, c->stream);
+    if ((rc = record(c, EV_PROBE1))) return rc;
+    HJ_HIP(c, hipGetLastError());
+    c->sSize += sSize;
+    return HJ_OK;
+}
+
+int hj_prj_join_dev(hj_ctx* c, const uint64_t* dR, uint64_t rSize, const uint64_t* dS, uint64_t sSize)
+{
+    if (!c || !dR || rSize == 0) return HJ_ERR_INVALID;
+    if (c->params.algo != HJ_ALGO_PRJ) return fail(c, HJ_ERR_STATE, "hj_prj_join_dev: context not reserved for PRJ");
+    const uint64_t nmax = rSize > sSize ? rSize : sSize;
+    if (nmax + 2 > c->capTmp || rSize + 2 > c->capPartR || (dS && sSize + 2 > c->capPartS))
+        return fail(c, HJ_ERR_STATE, "hj_prj_join_dev: hj_reserve() not called for these sizes");
+    HJ_HIP(c, hipSetDevice(c->device));
+    // the plan depends on the sizes (chunking); re-plan with the reserved bit count
+    const PrjPlan pl = prj_plan(rSize, dS ? sSize : 0, c->plan.radixBits);
+    if (pl.workspaceBytes > c->capWork) return fail(c, HJ_ERR_STATE, "hj_prj_join_dev: workspace too small");
+    for (bool& b : c->evSet) b = false;
+    c->built = false;
+    c->rSize = rSize; c->sSize = dS ? sSize : 0; c->tableSize = 0;
+    HJ_HIP(c, hipMemsetAsync(c->dCtr, 0, sizeof(Counters), c->stream));
+    int rc;
+    if ((rc = record(c, EV_PRJ0))) return rc;
+    PrjBuffers buf{c->tmpA, c->partR, c->partS, c->work};
+    launch_prj(pl, buf, dR, rSize, dS, dS ? sSize : 0, c->dCtr, c->ev[EV_PRJ_PART], c->stream);
+    c->evSet[EV_PRJ_PART] = true;
+    if ((rc = record(c, EV_PRJ1))) return rc;
+    HJ_HIP(c, hipGetLastError());
+    c->prjRan = true;
+    return HJ_OK;
+}
+
+int hj_checksums_dev(hj_ctx* c)
+{
+    if (!c) return HJ_ERR_INVALID;
+    if (!c->built) return fail(c, HJ_ERR_STATE, "hj_checksums_dev: no table");
+    HJ_HIP(c, hipSetDevice(c->device));
+    // zero the two sums so the call is idempotent
+    HJ_HIP(c, hipMemsetAsync(&c->dCtr->tableSumHalf, 0, 2 * sizeof(unsigned long long), c->stream));
+    launch_table_sums(c->table, c->tableSize, c->tableBase == 0 ? c->rSize : 0, c->dCtr, c->stream);
+    HJ_HIP(c, hipGetLastError());
+    return HJ_OK;
+}
+
+int hj_fetch_result(hj_ctx* c, hj_result* out)
+{
+    if (!c || !out) return HJ_ERR_INVALID;
+    HJ_HIP(c, hipSetDevice(c->device));
+    HJ_HIP(c, hipMemcpyAsync(c->hCtr, c->dCtr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+    HJ_HIP(c, hipStreamSynchronize(c->stream));
+    memset(out, 0, sizeof(*out));
+    const Counters& k = *c->hCtr;
+    out->rSize = c->rSize; out->sSize = c->sSize; out->tableSize = c->tableSize;
+    out->inputSum = k.inputSum;
+    if (c->prjRan) {
+        out->totalMatches = k.prjMatches;
+        out->prjChecksum = k.prjChecksum;
+        out->prjPartitions = 1ull << c->plan.radixBits;
+        out->radixBits = c->plan.radixBits;
+        out->partition_us = elapsed_us(c, EV_PRJ0, EV_PRJ_PART);
+        out->join_us = elapsed_us(c, EV_PRJ_PART, EV_PRJ1);
+        out->total_us = elapsed_us(c, EV_PRJ0, EV_PRJ1);
+    } else {
+        out->conflicts = k.conflicts;
+        out->conflictSum = k.conflictSum;
+        out->totalMatches = k.matches;
+        out->tableSumHalf = k.tableSumHalf;
+        out->tableSumFull = k.tableSumFull;
+        out->outputSum = (c->params.algo == HJ_ALGO_NOCC ? k.tableSumHalf : k.tableSumFull) + k.conflictSum;
+        out->buildVariant = 1;
+        out->clear_us = elapsed_us(c, EV_CLEAR0, EV_BUILD0);
+        out->build_us = elapsed_us(c, EV_BUILD0, EV_BUILD1);
+        out->probe_us = elapsed_us(c, EV_PROBE0, EV_PROBE1);
+        // the reference's timed region is build+probe, table zeroing excluded
+        // (NoCCHashBuild.hpp:24-34,83); clear_us is reported beside it
+        out->total_us = out->build_us + out->probe_us;
+    }
+    out->h2d_us = c->h2d_us;
+    if (k.badKeys) return fail(c, HJ_ERR_KEY_RANGE, "input holds tuples with payload bits set or value 0");
+    return HJ_OK;
+}
+
+int hj_export_table(hj_ctx* c, uint64_t* host_table, uint64_t tableSize)
+{
+    if (!c || !host_table) return HJ_ERR_INVALID;
+    if (!c->built || tableSize != c->tableSize) return fail(c, HJ_ERR_STATE, "hj_export_table: no table of that size");
+    HJ_HIP(c, hipSetDevice(c->device));
+    HJ_HIP(c, hipMemcpyAsync(host_table, c->table, tableSize * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HJ_HIP(c, hipStreamSynchronize(c->stream));
+    // device format (index << 32 | key, all ones = empty) -> reference format (key, 0 = empty)
+    for (uint64_t i = 0; i < tableSize; ++i)
+        host_table[i] = host_table[i] == kEmpty ? 0 : (uint32_t)host_table[i];
+    return HJ_OK;
+}
+
+int hj_run(hj_ctx* c, const hj_params* params, const uint64_t* relR, uint64_t rSize,
+           const uint64_t* relS, uint64_t sSize, hj_result* out)
+{
+    if (!c || !params || !relR || !out) return HJ_ERR_INVALID;
+    if (!relS) sSize = 0;
+    int rc;
+    if ((rc = hj_reserve(c, params, rSize, sSize))) return rc;
+    if ((rc = grow(c, c->stageR, c->capStageR, rSize + 2))) return rc;
+    if (sSize && (rc = grow(c, c->stageS, c->capStageS, sSize + 2))) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    HJ_HIP(c, hipMemcpyAsync(c->stageR, relR, rSize * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    if (sSize) HJ_HIP(c, hipMemcpyAsync(c->stageS, relS, sSize * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    HJ_HIP(c, hipStreamSynchronize(c->stream));
+    c->h2d_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    if (params->algo == HJ_ALGO_PRJ) {
+        if ((rc = hj_prj_join_dev(c, c->stageR, rSize, sSize ? c->stageS : nullptr, sSize))) return rc;
+    } else {
+        if ((rc = hj_build_dev(c, c->stageR, rSize, 0))) return rc;
+        if (sSize && (rc = hj_probe_dev(c, c->stageS, sSize))) return rc;
+        if ((rc = hj_checksums_dev(c))) return rc;
+    }
+    return hj_fetch_result(c, out);
+}
+
+// ---- shard helpers -----------------------------------------------------------
+int hj_shard_histogram_dev(hj_ctx* c, const uint64_t* dIn, uint64_t n, uint32_t nShards, uint32_t mode,
+                           uint64_t tableSize, uint64_t* dCounts)
+{
+    if (!c || (!dIn && n) || !dCounts) return HJ_ERR_INVALID;
+    if (!is_pow2(nShards) || nShards > 64 || mode > 1) return fail(c, HJ_ERR_INVALID, "hj_shard_histogram_dev: nShards must be a power of two <= 64");
+    if (mode == 1 && (!is_pow2(tableSize) || tableSize < nShards)) return fail(c, HJ_ERR_INVALID, "hj_shard_histogram_dev: tableSize");
+    if (mode == 0) tableSize = 1ull << 32;
+    HJ_HIP(c, hipSetDevice(c->device));
+    launch_shard_histogram(dIn, n, nShards, mode, tableSize, reinterpret_cast<unsigned long long*>(dCounts), c->stream);
+    HJ_HIP(c, hipGetLastError());
+    return HJ_OK;
+}
+
+int hj_shard_scatter_dev(hj_ctx* c, const uint64_t* dIn, uint64_t n, uint32_t nShards, uint32_t mode,
+                         uint64_t tableSize, const uint64_t* dCounts, uint64_t packIdxBase, uint64_t* dOut)
+{
+    if (!c || (!dIn && n) || !dCounts || (!dOut && n)) return HJ_ERR_INVALID;
+    if (!is_pow2(nShards) || nShards > 64 || mode > 1) return fail(c, HJ_ERR_INVALID, "hj_shard_scatter_dev: nShards must be a power of two <= 64");
+    if (mode == 1 && (!is_pow2(tableSize) || tableSize < nShards)) return fail(c, HJ_ERR_INVALID, "hj_shard_scatter_dev: tableSize");
+    if (packIdxBase != ~0ull && packIdxBase + n > (1ull << 32)) return fail(c, HJ_ERR_INVALID, "hj_shard_scatter_dev: index range exceeds 32 bits");
+    if (mode == 0) tableSize = 1ull << 32;
+    HJ_HIP(c, hipSetDevice(c->device));
+    launch_shard_scatter(dIn, n, nShards, mode, tableSize, reinterpret_cast<const unsigned long long*>(dCounts),
+                         c->shardCursors, packIdxBase, dOut, c->stream);
+    HJ_HIP(c, hipGetLastError());
+    return HJ_OK;
+}
+
+// ---- raw device memory ---------------------------------------------------------
+int hj_dev_alloc(hj_ctx* c, uint64_t bytes, void** dptr)
+{
+    if (!c || !dptr) return HJ_ERR_INVALID;
+    HJ_HIP(c, hipSetDevice(c->device));
+    HJ_HIP(c, hipMalloc(dptr, bytes ? bytes : 16));
+    return HJ_OK;
+}
+
+int hj_dev_free(hj_ctx* c, void* dptr)
+{
+    if (!c) return HJ_ERR_INVALID;
+    HJ_HIP(c, hipSetDevice(c->device));
+    HJ_HIP(c, hipStreamSynchronize(c->stream));
+    if (dptr) HJ_HIP(c, hipFree(dptr));
+    return HJ_OK;
+}
+
+int hj_copy_h2d(hj_ctx* c, void* dst_dev, const void* src_host, uint64_t bytes)
+{
+    if (!c || !dst_dev || !src_host) return HJ_ERR_INVALID;
+    HJ_HIP(c, hipSetDevice(c->device));
+    HJ_HIP(c, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream));
+    HJ_HIP(c, hipStreamSynchronize(c->stream));
+    return HJ_OK;
+}
+
+int hj_copy_d2h(hj_ctx* c, void* dst_host, const void* src_dev, uint64_t bytes)
+{
+    if (!c || !dst_host || !src_dev) return HJ_ERR_INVALID;
+    HJ_HIP(c, hipSetDevice(c->device));
+    HJ_HIP(c, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    HJ_HIP(c, hipStreamSynchronize(c->stream));
+    return HJ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,185 @@
+// hj_datagen.cpp -- the input layer: hj_generate_data(), a from-scratch equivalent
+// of generate_data() in the reference's include/DataGen.hpp:26-122.
+//
+// The reference draws from libc rand() after srand(0), so its inputs (and the
+// inputSum values in its logs) are a function of glibc's generator. To stay
+// bit-identical without going through libc's locked global state, GlibcRand
+// below restates that generator (glibc stdlib/random_r.c, TYPE_3: the additive
+// feedback r[i] = r[i-3] + r[i-31] over 31 words, seeded by the Lehmer LCG
+// 16807 mod 2^31-1, first 310 outputs discarded, result = r >> 1).
+// tests/test_datagen.py checks it against libc rand() itself.
+
+#include "../../include/htm_hashjoin.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace {
+
+class GlibcRand {
+  public:
+    explicit GlibcRand(unsigned seed) { reseed(seed); }
+    void reseed(unsigned seed)
+    {
+        if (seed == 0) seed = 1;
+        int32_t word = (int32_t)seed;
+        st_[0] = (uint32_t)word;
+        for (int i = 1; i < 31; ++i) {
+            const long hi = word / 127773, lo = word % 127773;
+            long w = 16807 * lo - 2836 * hi;
+            if (w < 0) w += 2147483647;
+            word = (int32_t)w;
+            st_[i] = (uint32_t)word;
+        }
+        f_ = 3; r_ = 0;
+        for (int k = 0; k < 310; ++k) (void)next();
+    }
+    inline int next()
+    {
+        const uint32_t v = (st_[f_] += st_[r_]);
+        if (++f_ >= 31) f_ = 0;
+        if (++r_ >= 31) r_ = 0;
+        return (int)(v >> 1);
+    }
+
+  private:
+    uint32_t st_[31];
+    int f_, r_;
+};
+
+constexpr int kRandMax = 2147483647;
+
+// Parallel LSD radix sort of values < 2^32 (11 bits x 3 passes). Any correct sort
+// gives std::sort's result on plain integers (DataGen.hpp:43,60).
+void sort_keys(uint64_t* a, uint64_t n)
+{
+    if (n < 2) return;
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 1;
+    if (nt > 32) nt = 32;
+    if (n < (1u << 16)) nt = 1;
+    std::vector<uint64_t> tmp(n);
+    uint64_t* src = a;
+    uint64_t* dst = tmp.data();
+    constexpr int kBits = 11, kFan = 1 << kBits;
+    uint64_t ormask = 0;
+    for (uint64_t i = 0; i < n; ++i) ormask |= a[i];
+    if (ormask >> 33) { std::sort(a, a + n); return; }  // not DataGen-shaped input
+    std::vector<uint64_t> hist((size_t)nt * kFan);
+    for (int shift = 0; shift < 33; shift += kBits) {
+        if (((ormask >> shift) & (kFan - 1)) == 0) continue;
+        std::fill(hist.begin(), hist.end(), 0);
+        auto range = [&](unsigned t, uint64_t& b, uint64_t& e) { b = n * t / nt; e = n * (t + 1) / nt; };
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t)
+            th.emplace_back([&, t] {
+                uint64_t b, e; range(t, b, e);
+                uint64_t* h = &hist[(size_t)t * kFan];
+                for (uint64_t i = b; i < e; ++i) h[(src[i] >> shift) & (kFan - 1)]++;
+            });
+        for (auto& x : th) x.join();
+        th.clear();
+        uint64_t sum = 0;  // digit-major, thread-minor prefix keeps the sort stable
+        for (int d = 0; d < kFan; ++d)
+            for (unsigned t = 0; t < nt; ++t) { uint64_t c = hist[(size_t)t * kFan + d]; hist[(size_t)t * kFan + d] = sum; sum += c; }
+        for (unsigned t = 0; t < nt; ++t)
+            th.emplace_back([&, t] {
+                uint64_t b, e; range(t, b, e);
+                uint64_t* h = &hist[(size_t)t * kFan];
+                for (uint64_t i = b; i < e; ++i) dst[h[(src[i] >> shift) & (kFan - 1)]++] = src[i];
+            });
+        for (auto& x : th) x.join();
+        std::swap(src, dst);
+    }
+    if (src != a) memcpy(a, src, n * sizeof(uint64_t));
+}
+
+// DataGen.hpp:44-54 / :61-71 / :97,107-115
+void window_shuffle(GlibcRand& rng, uint64_t* input, uint64_t n, int window)
+{
+    std::vector<unsigned char> shuffled(n ? n : 1, 0);
+    for (uint64_t i = 0; i + 1 < n; ++i) {
+        if (!shuffled[i]) {
+            const int rem = (int)(n - i);
+            const int swap = rng.next() % std::min(window, rem);
+            std::swap(input[i], input[i + swap]);
+            shuffled[i + swap] = 1;
+        }
+    }
+}
+
+void iota1(uint64_t* out, uint64_t n)  // DataGen.hpp:79-85
+{
+    for (uint64_t i = 0; i < n; ++i) out[i] = i + 1;
+}
+
+}  // namespace
+
+extern "C" int hj_generate_data(const char* dist, uint64_t n, uint64_t distinct, int window,
+                                double zipfTheta, uint64_t* out)
+{
+    if (!dist || (!out && n)) return HJ_ERR_INVALID;
+    GlibcRand rng(0);  // srand(0), DataGen.hpp:27
+    const uint32_t mod_mask = (uint32_t)(distinct - 1);
+    if (strcmp(dist, "uniform") == 0) {
+        if (window <= 0) return HJ_ERR_INVALID;
+        for (uint64_t i = 0; i < n; ++i) out[i] = ((uint32_t)rng.next() & mod_mask) + 1;
+        sort_keys(out, n);
+        window_shuffle(rng, out, n, window);
+    } else if (strcmp(dist, "random") == 0) {
+        if (window <= 0) return HJ_ERR_INVALID;
+        for (uint64_t i = 0; i < n; ++i) {
+            out[i] = (uint64_t)rng.next();
+            while (out[i] == 0) out[i] = (uint64_t)rng.next();
+        }
+        sort_keys(out, n);
+        window_shuffle(rng, out, n, window);
+    } else if (strcmp(dist, "sorted") == 0) {
+        iota1(out, n);
+    } else if (strcmp(dist, "shuffle") == 0) {
+        iota1(out, n);
+        // std::random_shuffle (libstdc++): j = rand() % (i + 1), swap(a[i], a[j])
+        for (uint64_t i = 1; i < n; ++i) {
+            const uint64_t j = (uint64_t)rng.next() % (i + 1);
+            if (i != j) std::swap(out[i], out[j]);
+        }
+    } else if (strcmp(dist, "local_shuffle") == 0) {
+        if (window <= 0) return HJ_ERR_INVALID;
+        iota1(out, n);
+        window_shuffle(rng, out, n, window);
+    } else if (strcmp(dist, "zipf") == 0) {
+        // mc/src/genzipf.c:28-151, keys over [1, distinct]; the reference DataGen
+        // branch (:72-77) is an empty stub, so the seed is ours: srand(0) like the rest
+        if (distinct == 0 || distinct > 0xFFFFFFFFull || !(zipfTheta >= 0.0)) return HJ_ERR_INVALID;
+        const uint32_t asz = (uint32_t)distinct;
+        std::vector<uint32_t> alphabet(asz);
+        for (uint32_t i = 0; i < asz; ++i) alphabet[i] = i + 1;
+        for (uint32_t i = asz - 1; i > 0; --i) {
+            const unsigned k = (unsigned)((unsigned long)i * (unsigned long)rng.next() / kRandMax);
+            std::swap(alphabet[i], alphabet[k]);
+        }
+        std::vector<double> lut(asz);
+        double scaling = 0.0, sum = 0.0;
+        for (uint32_t i = 1; i <= asz; ++i) scaling += 1.0 / std::pow((double)i, zipfTheta);
+        for (uint32_t i = 1; i <= asz; ++i) { sum += 1.0 / std::pow((double)i, zipfTheta); lut[i - 1] = sum / scaling; }
+        for (uint64_t i = 0; i < n; ++i) {
+            const double r = ((double)rng.next()) / kRandMax;
+            unsigned left = 0, right = asz - 1, pos;
+            if (lut[0] >= r) pos = 0;
+            else {
+                while (right - left > 1) {
+                    const unsigned m = (left + right) / 2;
+                    if (lut[m] < r) left = m; else right = m;
+                }
+                pos = right;
+            }
+            out[i] = alphabet[pos];
+        }
+    } else {
+        return HJ_ERR_INVALID;  // DataGen.hpp:116-119 prints "Unknown distribution" and exits
+    }
+    return HJ_OK;
+}

@@ -1,0 +1,76 @@
+// hj_device.h -- shared declarations between the HIP kernels (hj_kernels.hip,
+// hj_prj.hip) and the C-ABI implementation (hj_api.hip). gfx950 only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hj {
+
+// A table slot holds (inputIndex << 32 | key32). All-ones is "empty" so that a
+// 64-bit atomicMin implements index priority (smaller input index wins).
+constexpr uint64_t kEmpty = ~0ull;
+// Slots past tableSize that always stay empty: the probe walk does not wrap
+// (NoCCHashBuild.hpp:74-75 does curSlot++ without & tableMask).
+constexpr uint32_t kTableSlack = 16;
+
+constexpr int kBlock = 256;          // 4 wavefronts of 64
+constexpr int kWave = 64;
+
+// Device-resident counters, zeroed at the start of a build. One cache line
+// apart is not needed: each is touched once per wavefront at kernel end.
+struct Counters {
+    unsigned long long conflicts;
+    unsigned long long conflictSum;
+    unsigned long long inputSum;
+    unsigned long long matches;
+    unsigned long long tableSumHalf;
+    unsigned long long tableSumFull;
+    unsigned long long badKeys;      // tuples with payload bits set or value 0
+    unsigned long long prjMatches;
+    unsigned long long prjChecksum;
+    unsigned long long prjOverflowParts; // partitions joined in several LDS blocks
+    unsigned long long spare[6];
+};
+
+// ---- launch wrappers (defined in hj_kernels.hip) ---------------------------
+void launch_fill_empty(uint64_t* table, uint64_t nSlots, hipStream_t s);
+void launch_build_atomic_min(const uint64_t* R, uint64_t n, uint64_t* table,
+                             uint64_t tableSize, uint32_t probeLen, uint64_t idxBase,
+                             Counters* ctr, hipStream_t s);
+void launch_build_packed(const uint64_t* packed, uint64_t n, uint64_t* table,
+                         uint64_t globalTableSize, uint64_t slotBase, uint64_t sliceSlots,
+                         uint32_t probeLen, Counters* ctr, hipStream_t s);
+void launch_probe(const uint64_t* S, uint64_t n, const uint64_t* table,
+                  uint64_t tableSize, uint32_t probeLen, Counters* ctr, hipStream_t s);
+void launch_table_sums(const uint64_t* table, uint64_t tableSize, uint64_t halfSlots,
+                       Counters* ctr, hipStream_t s);
+void launch_shard_histogram(const uint64_t* in, uint64_t n, uint32_t nShards, uint32_t mode,
+                            uint64_t tableSize, unsigned long long* counts, hipStream_t s);
+void launch_shard_scatter(const uint64_t* in, uint64_t n, uint32_t nShards, uint32_t mode,
+                          uint64_t tableSize, const unsigned long long* counts,
+                          unsigned long long* cursors, uint64_t packIdxBase,
+                          uint64_t* out, hipStream_t s);
+
+// ---- PRJ (defined in hj_prj.hip) -------------------------------------------
+struct PrjPlan {
+    uint32_t radixBits;   // total
+    uint32_t bits1, bits2;
+    uint64_t maxChunks1, maxChunks2;   // chunk descriptors per pass (upper bounds)
+    size_t   workspaceBytes;           // everything below, excluding tuple buffers
+};
+// Sizes the workspace for (nR, nS).
+PrjPlan prj_plan(uint64_t nR, uint64_t nS, uint32_t radixBits);
+struct PrjBuffers {
+    uint64_t* tmpA;      // max(nR,nS) tuples
+    uint64_t* partR;     // nR tuples (final partitioned R)
+    uint64_t* partS;     // nS tuples
+    void*     work;      // plan.workspaceBytes
+};
+// Enqueues partition(R), partition(S) and the per-partition LDS join.
+// evPartDone (may be null) is recorded between partitioning and join.
+void launch_prj(const PrjPlan& plan, const PrjBuffers& buf,
+                const uint64_t* R, uint64_t nR, const uint64_t* S, uint64_t nS,
+                Counters* ctr, hipEvent_t evPartDone, hipStream_t s);
+
+}  // namespace hj

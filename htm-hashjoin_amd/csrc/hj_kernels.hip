@@ -1,0 +1,364 @@
+// hj_kernels.hip -- open-addressing build + probe kernels for gfx950 (MI355X).
+//
+// What these replace (reference paths relative to anilshanbhag/HTM-HashJoin):
+//   k_build_atomic_min  HOT LOOP 1, NoCCHashBuild.hpp:37-62 / AtomicHashBuild.hpp:37-67
+//                       (and the TSX group insert of HTMHashBuild.hpp:157-215, replaced outright)
+//   k_probe             HOT LOOP 2, NoCCHashBuild.hpp:66-80 / AtomicHashBuild.hpp:71-85
+//   k_table_sums        the untimed reductions, NoCCHashBuild.hpp:94-101 / AtomicHashBuild.hpp:100-107
+//
+// Semantics: the reference's parallel build is order dependent on duplicate
+// keys (racy store / first-come CAS). The well-defined result is the one a
+// single thread produces walking R in input order; these kernels reproduce
+// exactly that result under any scheduling:
+//   a slot holds (inputIndex << 32 | key), empty = all ones, and a tuple claims
+//   a slot with a 64-bit atomicMin. If the previous holder had a larger index it
+//   is displaced and re-inserted from the next slot with the budget it has left
+//   (its displacement from its home slot is recoverable from slot and key);
+//   if it had a smaller index the newcomer moves on. Slot values only ever
+//   decrease, so the fixed point is unique: every tuple ends in the first slot
+//   of its probe window that no smaller-indexed tuple finally occupies, which
+//   is where sequential insertion puts it; tuples that run out of budget are
+//   the sequential run's conflicts.
+//
+// All integer work, HBM/atomic bound; no MFMA.
+
+#include "hj_device.h"
+
+namespace hj {
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;  // valid in lane 0
+}
+
+// Adds each wavefront's partial sums to the global counters, one atomic per
+// wavefront and counter (skipped when the wavefront has nothing to add).
+__device__ __forceinline__ void flush_counter(unsigned long long* dst, unsigned long long v)
+{
+    v = wave_sum(v);
+    if ((threadIdx.x & (kWave - 1)) == 0 && v != 0) atomicAdd(dst, v);
+}
+
+static inline unsigned grid_for(uint64_t items, unsigned perBlock)
+{
+    uint64_t blocks = (items + perBlock - 1) / perBlock;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256u * 8u) blocks = 256u * 8u;  // 256 CUs x 8 blocks, grid-stride the rest
+    return (unsigned)blocks;
+}
+
+// ---------------------------------------------------------------------------
+// table clear: 16-byte stores of the empty pattern
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_fill_empty(uint64_t* __restrict__ table, uint64_t nSlots)
+{
+    // table is hipMalloc'ed (256-B aligned); nSlots is even by construction
+    ulonglong2* t2 = reinterpret_cast<ulonglong2*>(table);
+    const uint64_t nv = nSlots >> 1;
+    const ulonglong2 e = make_ulonglong2(kEmpty, kEmpty);
+    for (uint64_t v = (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (uint64_t)gridDim.x * kBlock)
+        t2[v] = e;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (nSlots & 1)) table[nSlots - 1] = kEmpty;
+}
+
+void launch_fill_empty(uint64_t* table, uint64_t nSlots, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_fill_empty, dim3(grid_for(nSlots / 2, kBlock * 4)), dim3(kBlock), 0, s, table, nSlots);
+}
+
+// ---------------------------------------------------------------------------
+// build
+// ---------------------------------------------------------------------------
+// Inserts `mine` starting at slot `pos` with `budget` probes left. `base` is
+// subtracted from a global slot number to index this table (0 for a whole
+// table; slotBase for a slice), and homeMask is globalTableSize-1.
+__device__ __forceinline__ void insert_priority(uint64_t* __restrict__ table, uint64_t homeMask,
+                                                uint64_t base, uint32_t probeLen,
+                                                uint64_t mine, uint64_t pos, uint32_t budget,
+                                                unsigned long long& drops, unsigned long long& dropSum)
+{
+    for (;;) {
+        if (budget == 0) {  // NoCCHashBuild.hpp:57-58
+            drops += 1;
+            dropSum += (uint32_t)mine;
+            return;
+        }
+        const unsigned long long old =
+            atomicMin(reinterpret_cast<unsigned long long*>(table + (pos - base)), (unsigned long long)mine);
+        if (old == kEmpty || old == mine) return;  // claimed an empty slot
+        if (old > mine) {
+            // displaced a later tuple: carry it on from the next slot with the
+            // budget it has left there
+            mine = old;
+            const uint64_t home = (uint32_t)old & homeMask;
+            const uint32_t disp = (uint32_t)((pos - home) & homeMask);
+            budget = probeLen - (disp + 1);
+        } else {
+            budget -= 1;  // occupied by an earlier tuple: NoCCHashBuild.hpp:50-53
+        }
+        pos = (pos + 1) & homeMask;
+    }
+}
+
+__device__ __forceinline__ void build_one(uint64_t t, uint64_t idx, uint64_t* __restrict__ table,
+                                          uint64_t mask, uint32_t probeLen,
+                                          unsigned long long& drops, unsigned long long& dropSum,
+                                          unsigned long long& inSum, unsigned long long& bad)
+{
+    inSum += t;
+    if ((t >> 32) != 0 || t == 0) { bad += 1; return; }
+    const uint64_t mine = (idx << 32) | t;
+    insert_priority(table, mask, 0, probeLen, mine, t & mask, probeLen, drops, dropSum);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_build_atomic_min(const uint64_t* __restrict__ R, uint64_t n, uint64_t* __restrict__ table,
+                   uint64_t mask, uint32_t probeLen, uint64_t idxBase, Counters* __restrict__ ctr)
+{
+    unsigned long long drops = 0, dropSum = 0, inSum = 0, bad = 0;
+    // 16-byte loads over the aligned body; head/tail element by one thread
+    const uint64_t head = (n > 0 && (reinterpret_cast<uintptr_t>(R) & 8)) ? 1 : 0;
+    const ulonglong2* R2 = reinterpret_cast<const ulonglong2*>(R + head);
+    const uint64_t nv = (n - head) >> 1;
+    for (uint64_t v = (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (uint64_t)gridDim.x * kBlock) {
+        const ulonglong2 t = R2[v];
+        const uint64_t i = head + 2 * v;
+        build_one(t.x, idxBase + i, table, mask, probeLen, drops, dropSum, inSum, bad);
+        build_one(t.y, idxBase + i + 1, table, mask, probeLen, drops, dropSum, inSum, bad);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (head) build_one(R[0], idxBase, table, mask, probeLen, drops, dropSum, inSum, bad);
+        const uint64_t tail = head + 2 * nv;
+        if (tail < n) build_one(R[tail], idxBase + tail, table, mask, probeLen, drops, dropSum, inSum, bad);
+    }
+    flush_counter(&ctr->conflicts, drops);
+    flush_counter(&ctr->conflictSum, dropSum);
+    flush_counter(&ctr->inputSum, inSum);
+    flush_counter(&ctr->badKeys, bad);
+}
+
+void launch_build_atomic_min(const uint64_t* R, uint64_t n, uint64_t* table, uint64_t tableSize,
+                             uint32_t probeLen, uint64_t idxBase, Counters* ctr, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_build_atomic_min, dim3(grid_for(n / 2 + 1, kBlock)), dim3(kBlock), 0, s,
+                       R, n, table, tableSize - 1, probeLen, idxBase, ctr);
+}
+
+// Build from pre-packed (globalIdx << 32 | key) tuples into a slice of a
+// global table (multi-GPU range sharding). Slots at or past the slice end are
+// the halo: the slice is allocated with kTableSlack extra slots for them.
+__global__ void __launch_bounds__(kBlock)
+k_build_packed(const uint64_t* __restrict__ P, uint64_t n, uint64_t* __restrict__ table,
+               uint64_t homeMask, uint64_t slotBase, uint32_t probeLen, Counters* __restrict__ ctr)
+{
+    unsigned long long drops = 0, dropSum = 0, inSum = 0, bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t p = P[i];
+        const uint32_t key = (uint32_t)p;
+        inSum += key;
+        if (key == 0) { bad += 1; continue; }
+        insert_priority(table, homeMask, slotBase, probeLen, p, key & homeMask, probeLen, drops, dropSum);
+    }
+    flush_counter(&ctr->conflicts, drops);
+    flush_counter(&ctr->conflictSum, dropSum);
+    flush_counter(&ctr->inputSum, inSum);
+    flush_counter(&ctr->badKeys, bad);
+}
+
+void launch_build_packed(const uint64_t* packed, uint64_t n, uint64_t* table, uint64_t globalTableSize,
+                         uint64_t slotBase, uint64_t /*sliceSlots*/, uint32_t probeLen, Counters* ctr,
+                         hipStream_t s)
+{
+    hipLaunchKernelGGL(k_build_packed, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s,
+                       packed, n, table, globalTableSize - 1, slotBase, probeLen, ctr);
+}
+
+// ---------------------------------------------------------------------------
+// probe
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t probe_one(uint64_t sk, const uint64_t* __restrict__ table,
+                                              uint64_t mask, uint32_t probeLen)
+{
+    // NoCCHashBuild.hpp:70-79: walk at most probeLen consecutive slots from the
+    // home slot, stop at the first empty one, count slots equal to the tuple.
+    const uint64_t* p = table + (sk & mask);
+    uint32_t m = 0;
+    if (probeLen == 4) {
+        const uint64_t a = p[0], b = p[1], c = p[2], d = p[3];  // slack slots make this safe
+        const bool ea = a != kEmpty, eb = ea && b != kEmpty, ec = eb && c != kEmpty, ed = ec && d != kEmpty;
+        m += (ea && (uint64_t)(uint32_t)a == sk);
+        m += (eb && (uint64_t)(uint32_t)b == sk);
+        m += (ec && (uint64_t)(uint32_t)c == sk);
+        m += (ed && (uint64_t)(uint32_t)d == sk);
+    } else {
+        for (uint32_t j = 0; j < probeLen; ++j) {
+            const uint64_t v = p[j];
+            if (v == kEmpty) break;
+            m += ((uint64_t)(uint32_t)v == sk);
+        }
+    }
+    return m;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_probe(const uint64_t* __restrict__ S, uint64_t n, const uint64_t* __restrict__ table, uint64_t mask,
+        uint32_t probeLen, Counters* __restrict__ ctr)
+{
+    unsigned long long matches = 0;
+    const uint64_t head = (n > 0 && (reinterpret_cast<uintptr_t>(S) & 8)) ? 1 : 0;
+    const ulonglong2* S2 = reinterpret_cast<const ulonglong2*>(S + head);
+    const uint64_t nv = (n - head) >> 1;
+    for (uint64_t v = (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (uint64_t)gridDim.x * kBlock) {
+        const ulonglong2 t = S2[v];
+        matches += probe_one(t.x, table, mask, probeLen);
+        matches += probe_one(t.y, table, mask, probeLen);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (head) matches += probe_one(S[0], table, mask, probeLen);
+        const uint64_t tail = head + 2 * nv;
+        if (tail < n) matches += probe_one(S[tail], table, mask, probeLen);
+    }
+    flush_counter(&ctr->matches, matches);
+}
+
+void launch_probe(const uint64_t* S, uint64_t n, const uint64_t* table, uint64_t tableSize,
+                  uint32_t probeLen, Counters* ctr, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_probe, dim3(grid_for(n / 2 + 1, kBlock)), dim3(kBlock), 0, s,
+                       S, n, table, tableSize - 1, probeLen, ctr);
+}
+
+// ---------------------------------------------------------------------------
+// table checksums
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_table_sums(const uint64_t* __restrict__ table, uint64_t tableSize, uint64_t halfSlots,
+             Counters* __restrict__ ctr)
+{
+    unsigned long long half = 0, full = 0;
+    const ulonglong2* t2 = reinterpret_cast<const ulonglong2*>(table);
+    const uint64_t nv = tableSize >> 1;  // tableSize = 2*rSize is even
+    for (uint64_t v = (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (uint64_t)gridDim.x * kBlock) {
+        const ulonglong2 t = t2[v];
+        const uint64_t a = (t.x == kEmpty) ? 0 : (uint32_t)t.x;
+        const uint64_t b = (t.y == kEmpty) ? 0 : (uint32_t)t.y;
+        full += a + b;
+        if (2 * v < halfSlots) half += a;
+        if (2 * v + 1 < halfSlots) half += b;
+    }
+    flush_counter(&ctr->tableSumHalf, half);
+    flush_counter(&ctr->tableSumFull, full);
+}
+
+void launch_table_sums(const uint64_t* table, uint64_t tableSize, uint64_t halfSlots, Counters* ctr,
+                       hipStream_t s)
+{
+    hipLaunchKernelGGL(k_table_sums, dim3(grid_for(tableSize / 2, kBlock * 4)), dim3(kBlock), 0, s,
+                       table, tableSize, halfSlots, ctr);
+}
+
+// ---------------------------------------------------------------------------
+// multi-GPU shard helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t shard_of(uint64_t t, uint32_t shardMask, uint32_t mode,
+                                             uint64_t tableMask, uint32_t rangeShift)
+{
+    // mode 0: low key bits (HASH_BIT_MODULO, parallel_radix_join.c:59)
+    // mode 1: high bits of the home slot (keeps probe windows on one shard)
+    return mode == 0 ? ((uint32_t)t & shardMask) : (uint32_t)((t & tableMask) >> rangeShift);
+}
+
+constexpr int kShardMax = 64;
+constexpr int kShardPerThread = 8;
+
+__global__ void __launch_bounds__(kBlock)
+k_shard_histogram(const uint64_t* __restrict__ in, uint64_t n, uint32_t nShards, uint32_t mode,
+                  uint64_t tableMask, uint32_t rangeShift, unsigned long long* __restrict__ counts)
+{
+    __shared__ unsigned int h[kShardMax];
+    if (threadIdx.x < kShardMax) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t shardMask = nShards - 1;
+    // each block owns contiguous tiles so that per-block counts fit 32 bits
+    const uint64_t tile = (uint64_t)kBlock * kShardPerThread;
+    for (uint64_t base = (uint64_t)blockIdx.x * tile; base < n; base += (uint64_t)gridDim.x * tile) {
+#pragma unroll
+        for (int k = 0; k < kShardPerThread; ++k) {
+            const uint64_t i = base + (uint64_t)k * kBlock + threadIdx.x;
+            if (i < n) atomicAdd(&h[shard_of(in[i], shardMask, mode, tableMask, rangeShift)], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < nShards && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_shard_scatter(const uint64_t* __restrict__ in, uint64_t n, uint32_t nShards, uint32_t mode,
+                uint64_t tableMask, uint32_t rangeShift, unsigned long long* __restrict__ cursors,
+                uint64_t packIdxBase, uint64_t* __restrict__ out)
+{
+    __shared__ unsigned int cnt[kShardMax];
+    __shared__ unsigned long long base[kShardMax];
+    const uint32_t shardMask = nShards - 1;
+    const uint64_t tile = (uint64_t)kBlock * kShardPerThread;
+    for (uint64_t t0 = (uint64_t)blockIdx.x * tile; t0 < n; t0 += (uint64_t)gridDim.x * tile) {
+        if (threadIdx.x < kShardMax) cnt[threadIdx.x] = 0;
+        __syncthreads();
+        uint64_t v[kShardPerThread];
+        uint32_t d[kShardPerThread], r[kShardPerThread];
+#pragma unroll
+        for (int k = 0; k < kShardPerThread; ++k) {
+            const uint64_t i = t0 + (uint64_t)k * kBlock + threadIdx.x;
+            d[k] = 0xFFFFFFFFu;
+            if (i < n) {
+                const uint64_t t = in[i];
+                d[k] = shard_of(t, shardMask, mode, tableMask, rangeShift);
+                r[k] = atomicAdd(&cnt[d[k]], 1u);
+                v[k] = (packIdxBase == ~0ull) ? t : (((packIdxBase + i) << 32) | (uint32_t)t);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < nShards && cnt[threadIdx.x])
+            base[threadIdx.x] = atomicAdd(&cursors[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kShardPerThread; ++k)
+            if (d[k] != 0xFFFFFFFFu) out[base[d[k]] + r[k]] = v[k];
+        __syncthreads();
+    }
+}
+
+// cursors[d] = exclusive prefix of counts (nShards <= 64: one wavefront)
+__global__ void k_shard_prefix(const unsigned long long* __restrict__ counts, uint32_t nShards,
+                               unsigned long long* __restrict__ cursors)
+{
+    if (threadIdx.x == 0) {
+        unsigned long long s = 0;
+        for (uint32_t d = 0; d < nShards; ++d) { cursors[d] = s; s += counts[d]; }
+    }
+}
+
+static uint32_t log2u64(uint64_t v) { uint32_t l = 0; while ((1ull << l) < v) ++l; return l; }
+
+void launch_shard_histogram(const uint64_t* in, uint64_t n, uint32_t nShards, uint32_t mode,
+                            uint64_t tableSize, unsigned long long* counts, hipStream_t s)
+{
+    hipMemsetAsync(counts, 0, sizeof(unsigned long long) * nShards, s);
+    const uint32_t shift = log2u64(tableSize) - log2u64(nShards);
+    hipLaunchKernelGGL(k_shard_histogram, dim3(grid_for(n, kBlock * kShardPerThread)), dim3(kBlock), 0, s,
+                       in, n, nShards, mode, tableSize - 1, shift, counts);
+}
+
+void launch_shard_scatter(const uint64_t* in, uint64_t n, uint32_t nShards, uint32_t mode,
+                          uint64_t tableSize, const unsigned long long* counts,
+                          unsigned long long* cursors, uint64_t packIdxBase, uint64_t* out, hipStream_t s)
+{
+    const uint32_t shift = log2u64(tableSize) - log2u64(nShards);
+    hipLaunchKernelGGL(k_shard_prefix, dim3(1), dim3(64), 0, s, counts, nShards, cursors);
+    hipLaunchKernelGGL(k_shard_scatter, dim3(grid_for(n, kBlock * kShardPerThread)), dim3(kBlock), 0, s,
+                       in, n, nShards, mode, tableSize - 1, shift, cursors, packIdxBase, out);
+}
+
+}  // namespace hj

@@ -1,0 +1,470 @@
+// hj_prj.hip -- radix-partitioned join (PRJ path) for gfx950 (MI355X).
+//
+// What this replaces (paths relative to anilshanbhag/HTM-HashJoin, mc/src/):
+//   k_radix_hist     the histogram loops of parallel_radix_partition (:586-589) and
+//                    radix_cluster (:418-421)
+//   k_scan_*         the prefix / cursor computation (:592-617, :423-430)
+//   k_radix_scatter  the scatter loops (:622-626, :433-437), here staged through LDS so
+//                    every partition's tuples leave the CU as contiguous runs
+//   k_prj_join       bucket_chaining_join (:231-283) with the probe loop the fork
+//                    commented out (:259-276) restored; the table lives in LDS
+// Orchestration (prj_thread :808-1122: 6 pthread barriers, 2 task queues) becomes
+// stream order between kernels.
+//
+// Partition function: HASH_BIT_MODULO(key, MASK, R) = (key & MASK) >> R on the low
+// 32 bits of the tuple (tuple_t.key), pass 1 on bits [0, bits1), pass 2 on
+// [bits1, bits1+bits2), bits1 = radixBits/2 as in prj_thread :814-816. The final
+// partition id is (pass-1 bin << bits2) | pass-2 bin, the same order the
+// reference's task queues visit them in.
+//
+// Layout: a pass works on "segments" (pass 1: the whole relation; pass 2: each
+// pass-1 partition). Segments are cut into chunks of chunkLen tuples; a workgroup
+// owns one chunk. Histogram entries are stored [segment][bin][chunk] so that one
+// exclusive scan over the whole array yields every chunk's write cursor.
+
+#include "hj_device.h"
+
+namespace hj {
+
+constexpr int kTileVec = 8;                       // 16-byte loads per thread per tile
+constexpr int kTile = kBlock * kTileVec * 2;      // 4096 tuples = 32 KiB staged in LDS
+constexpr int kMaxFan = 256;                      // <= 8 radix bits per pass
+constexpr uint32_t kJoinSlots = 32768;            // LDS table slots (uint32) = 128 KiB
+constexpr uint32_t kJoinBlockTuples = 24576;      // R tuples per LDS build (load <= 0.75)
+constexpr int kJoinThreads = 1024;
+constexpr uint32_t kEmpty32 = 0xFFFFFFFFu;
+
+struct PassParams {
+    const uint32_t* segOff;     // [nSeg + 1] tuple offsets of the input segments
+    uint32_t nSeg;
+    uint32_t chunkLen;          // multiple of kTile
+    const uint32_t* chunkBase;  // [nSeg + 1] exclusive prefix of chunks per segment
+    uint32_t shift, fan;        // bin = (key >> shift) & (fan - 1)
+};
+
+// chunkBase[s] = sum_{t<s} ceil(len_t / chunkLen). nSeg <= 256: one thread.
+__global__ void k_chunk_base(const uint32_t* __restrict__ segOff, uint32_t nSeg, uint32_t chunkLen,
+                             uint32_t* __restrict__ chunkBase)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint32_t acc = 0;
+        for (uint32_t s = 0; s < nSeg; ++s) {
+            chunkBase[s] = acc;
+            const uint32_t len = segOff[s + 1] - segOff[s];
+            acc += (len + chunkLen - 1) / chunkLen;
+        }
+        chunkBase[nSeg] = acc;
+    }
+}
+
+__global__ void k_init_seg(uint32_t* seg, uint32_t n)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) { seg[0] = 0; seg[1] = n; }
+}
+
+// Finds the segment of chunk c (largest s with chunkBase[s] <= c). Wave-uniform.
+__device__ __forceinline__ uint32_t find_segment(const uint32_t* __restrict__ chunkBase, uint32_t nSeg, uint32_t c)
+{
+    uint32_t lo = 0, hi = nSeg;  // invariant: chunkBase[lo] <= c < chunkBase[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (chunkBase[mid] <= c) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+struct ChunkRange { uint32_t seg, local, nLocal, begin, end; };
+
+__device__ __forceinline__ ChunkRange chunk_range(const PassParams& p, uint32_t c)
+{
+    ChunkRange r;
+    r.seg = find_segment(p.chunkBase, p.nSeg, c);
+    r.local = c - p.chunkBase[r.seg];
+    r.nLocal = p.chunkBase[r.seg + 1] - p.chunkBase[r.seg];
+    const uint32_t sb = p.segOff[r.seg], se = p.segOff[r.seg + 1];
+    r.begin = sb + r.local * p.chunkLen;
+    const uint64_t e = (uint64_t)r.begin + p.chunkLen;
+    r.end = e < se ? (uint32_t)e : se;
+    return r;
+}
+
+// hist index of (segment, bin, local chunk)
+__device__ __forceinline__ uint64_t hist_index(const PassParams& p, const ChunkRange& r, uint32_t bin)
+{
+    return (uint64_t)p.chunkBase[r.seg] * p.fan + (uint64_t)bin * r.nLocal + r.local;
+}
+
+// ---------------------------------------------------------------------------
+// histogram
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_radix_hist(const uint64_t* __restrict__ in, PassParams p, uint32_t* __restrict__ hist)
+{
+    __shared__ unsigned int h[kMaxFan];
+    const uint32_t c = blockIdx.x;
+    if (c >= p.chunkBase[p.nSeg]) return;
+    const ChunkRange r = chunk_range(p, c);
+    if (threadIdx.x < kMaxFan) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t fmask = p.fan - 1;
+    // 16-byte aligned sweep: start at the even tuple at or below begin
+    const uint32_t b0 = r.begin & ~1u;
+    const ulonglong2* in2 = reinterpret_cast<const ulonglong2*>(in);
+    for (uint32_t v = (b0 >> 1) + threadIdx.x; 2 * (uint64_t)v < r.end; v += kBlock) {
+        const ulonglong2 t = in2[v];
+        const uint32_t i = 2 * v;
+        if (i >= r.begin) atomicAdd(&h[((uint32_t)t.x >> p.shift) & fmask], 1u);
+        if (i + 1 >= r.begin && i + 1 < r.end) atomicAdd(&h[((uint32_t)t.y >> p.shift) & fmask], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < p.fan) hist[hist_index(p, r, threadIdx.x)] = h[threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------
+// exclusive scan of a uint32 array (3 kernels: block scan, scan of block sums, add)
+// ---------------------------------------------------------------------------
+constexpr int kScanPerThread = 16;
+constexpr int kScanTile = kBlock * kScanPerThread;  // 4096
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* wsum /*[kBlock/64]*/, uint32_t& total)
+{
+    // inclusive scan inside the wavefront
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t n = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += n;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < kBlock / 64; ++k) {
+        const uint32_t s = wsum[k];
+        if (k < w) wbase += s;
+        tot += s;
+    }
+    total = tot;
+    __syncthreads();
+    return wbase + inc - v;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_scan_blocks(uint32_t* __restrict__ data, uint64_t n, uint32_t* __restrict__ blockSums)
+{
+    __shared__ uint32_t wsum[kBlock / 64];
+    const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanPerThread;
+    uint32_t v[kScanPerThread], local = 0;
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; ++k) {
+        v[k] = (base + k < n) ? data[base + k] : 0;
+        local += v[k];
+    }
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan(local, wsum, total);
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; ++k) {
+        if (base + k < n) data[base + k] = ex;
+        ex += v[k];
+    }
+    if (threadIdx.x == 0) blockSums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_scan_sums(uint32_t* __restrict__ sums, uint32_t m)
+{
+    __shared__ uint32_t wsum[kBlock / 64];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < m; base += kBlock) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < m ? sums[i] : 0;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan(v, wsum, total);
+        if (i < m) sums[i] = carry + ex;
+        carry += total;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_scan_add(uint32_t* __restrict__ data, uint64_t n, const uint32_t* __restrict__ blockSums)
+{
+    const uint32_t add = blockSums[blockIdx.x];
+    const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanPerThread;
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; ++k)
+        if (base + k < n) data[base + k] += add;
+}
+
+// New segment offsets after a pass: segOut[s*fan + bin] = start of that bin.
+__global__ void __launch_bounds__(kBlock)
+k_seg_offsets(PassParams p, const uint32_t* __restrict__ scanned, uint32_t nTotal, uint32_t* __restrict__ segOut)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t total = p.nSeg * p.fan;
+    if (i == total) segOut[i] = nTotal;
+    if (i >= total) return;
+    const uint32_t s = i / p.fan, bin = i - s * p.fan;
+    const uint32_t nLocal = p.chunkBase[s + 1] - p.chunkBase[s];
+    // an empty segment has no histogram entries: all its bins start where it starts
+    segOut[i] = nLocal ? scanned[(uint64_t)p.chunkBase[s] * p.fan + (uint64_t)bin * nLocal] : p.segOff[s];
+}
+
+// ---------------------------------------------------------------------------
+// scatter: tile-local counting sort in LDS, then contiguous runs to HBM
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_radix_scatter(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, PassParams p,
+                const uint32_t* __restrict__ scanned)
+{
+    __shared__ uint64_t stage[kTile];            // 32 KiB
+    __shared__ unsigned int tileCnt[kMaxFan];
+    __shared__ unsigned int tileOff[kMaxFan];
+    __shared__ unsigned int cursor[kMaxFan];
+    __shared__ uint32_t wsum[kBlock / 64];
+
+    const uint32_t c = blockIdx.x;
+    if (c >= p.chunkBase[p.nSeg]) return;
+    const ChunkRange r = chunk_range(p, c);
+    const uint32_t fmask = p.fan - 1;
+    if (threadIdx.x < p.fan) cursor[threadIdx.x] = scanned[hist_index(p, r, threadIdx.x)];
+
+    const ulonglong2* in2 = reinterpret_cast<const ulonglong2*>(in);
+    const uint32_t b0 = r.begin & ~1u;
+    for (uint64_t tb = b0; tb < r.end; tb += kTile) {
+        if (threadIdx.x < kMaxFan) tileCnt[threadIdx.x] = 0;
+        __syncthreads();
+        uint64_t tv[2 * kTileVec];
+        uint32_t br[2 * kTileVec];  // bin << 16 | rank within (tile, bin); rank < 4096
+#pragma unroll
+        for (int k = 0; k < kTileVec; ++k) {
+            const uint64_t i = tb + 2 * ((uint64_t)k * kBlock + threadIdx.x);
+            ulonglong2 t = make_ulonglong2(0, 0);
+            if (i < r.end) t = in2[i >> 1];
+            tv[2 * k] = t.x; tv[2 * k + 1] = t.y;
+            br[2 * k] = br[2 * k + 1] = 0xFFFFFFFFu;
+            if (i >= r.begin && i < r.end) {
+                const uint32_t bin = ((uint32_t)t.x >> p.shift) & fmask;
+                br[2 * k] = (bin << 16) | atomicAdd(&tileCnt[bin], 1u);
+            }
+            if (i + 1 >= r.begin && i + 1 < r.end) {
+                const uint32_t bin = ((uint32_t)t.y >> p.shift) & fmask;
+                br[2 * k + 1] = (bin << 16) | atomicAdd(&tileCnt[bin], 1u);
+            }
+        }
+        __syncthreads();
+        {   // exclusive scan of tileCnt[0..fan) (fan <= 256 = one value per thread)
+            const uint32_t v = threadIdx.x < p.fan ? tileCnt[threadIdx.x] : 0;
+            uint32_t total;
+            const uint32_t ex = block_exclusive_scan(v, wsum, total);
+            if (threadIdx.x < kMaxFan) tileOff[threadIdx.x] = ex;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2 * kTileVec; ++k)
+            if (br[k] != 0xFFFFFFFFu) stage[tileOff[br[k] >> 16] + (br[k] & 0xFFFFu)] = tv[k];
+        __syncthreads();
+        const uint32_t valid = tileOff[p.fan - 1] + tileCnt[p.fan - 1];
+#pragma unroll
+        for (int k = 0; k < 2 * kTileVec; ++k) {
+            const uint32_t q = (uint32_t)k * kBlock + threadIdx.x;
+            if (q < valid) {
+                const uint64_t t = stage[q];
+                const uint32_t bin = ((uint32_t)t >> p.shift) & fmask;
+                out[cursor[bin] + (q - tileOff[bin])] = t;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < p.fan) cursor[threadIdx.x] += tileCnt[threadIdx.x];
+        // (next iteration's first barrier orders the cursor update)
+    }
+}
+
+// ---------------------------------------------------------------------------
+// per-partition join in LDS
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t next_pow2_u32(uint32_t v)
+{
+    // NEXT_POW_2, parallel_radix_join.c:66-76
+    v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; v++;
+    return v;
+}
+
+__global__ void __launch_bounds__(kJoinThreads)
+k_prj_join(const uint64_t* __restrict__ partR, const uint32_t* __restrict__ offR,
+           const uint64_t* __restrict__ partS, const uint32_t* __restrict__ offS,
+           uint32_t radixBits, Counters* __restrict__ ctr)
+{
+    extern __shared__ uint32_t tab[];  // kJoinSlots
+    const uint32_t pid = blockIdx.x;
+    const uint32_t rb = offR[pid], re = offR[pid + 1];
+    const uint32_t nR = re - rb;
+    if (nR == 0) return;  // serial_radix_partition :531 queues only non-empty R parts
+    const uint32_t sb = partS ? offS[pid] : 0, se = partS ? offS[pid + 1] : 0;
+    const uint32_t idxMask = next_pow2_u32(nR) - 1;  // bucket idx mask, :242-245
+    unsigned long long matches = 0, checksum = 0;
+
+    for (uint32_t blk = rb; blk < re; blk += kJoinBlockTuples) {
+        const uint32_t bend = (re - blk > kJoinBlockTuples) ? blk + kJoinBlockTuples : re;
+        for (uint32_t i = threadIdx.x; i < kJoinSlots; i += kJoinThreads) tab[i] = kEmpty32;
+        __syncthreads();
+        for (uint32_t i = blk + threadIdx.x; i < bend; i += kJoinThreads) {
+            const uint32_t k = (uint32_t)partR[i] >> radixBits;  // distinguishes keys inside a partition
+            checksum += k & idxMask;                              // :249,256
+            uint32_t h = k & (kJoinSlots - 1);
+            while (atomicCAS(&tab[h], kEmpty32, k) != kEmpty32) h = (h + 1) & (kJoinSlots - 1);
+        }
+        __syncthreads();
+        for (uint32_t i = sb + threadIdx.x; i < se; i += kJoinThreads) {
+            const uint32_t k = (uint32_t)partS[i] >> radixBits;
+            uint32_t h = k & (kJoinSlots - 1);
+            for (;;) {
+                const uint32_t v = tab[h];
+                if (v == kEmpty32) break;
+                matches += (v == k);                              // :268-271
+                h = (h + 1) & (kJoinSlots - 1);
+            }
+        }
+        __syncthreads();
+    }
+    // one atomic per wavefront
+    for (int off = 32; off > 0; off >>= 1) {
+        matches += __shfl_down(matches, off, 64);
+        checksum += __shfl_down(checksum, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (matches) atomicAdd(&ctr->prjMatches, matches);
+        if (checksum) atomicAdd(&ctr->prjChecksum, checksum);
+    }
+    if (threadIdx.x == 0 && nR > kJoinBlockTuples) atomicAdd(&ctr->prjOverflowParts, 1ull);
+}
+
+// ---------------------------------------------------------------------------
+// host-side planning and launch
+// ---------------------------------------------------------------------------
+static uint32_t pick_chunk_len(uint64_t n)
+{
+    // aim for ~4096 chunks (>= 2 per CU-slot), whole tiles, 4Ki..64Ki tuples
+    uint64_t len = n / 4096;
+    len = (len + kTile - 1) / kTile * kTile;
+    if (len < (uint64_t)kTile) len = kTile;
+    if (len > 65536) len = 65536;
+    return (uint32_t)len;
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct PassLayout { uint32_t chunkLen; uint64_t maxChunks; uint64_t histEntries; uint64_t scanBlocks; };
+
+static PassLayout pass_layout(uint64_t n, uint32_t nSeg, uint32_t fan)
+{
+    PassLayout l;
+    l.chunkLen = pick_chunk_len(n);
+    l.maxChunks = n / l.chunkLen + nSeg + 1;
+    l.histEntries = l.maxChunks * fan;
+    l.scanBlocks = (l.histEntries + kScanTile - 1) / kScanTile;
+    return l;
+}
+
+PrjPlan prj_plan(uint64_t nR, uint64_t nS, uint32_t radixBits)
+{
+    PrjPlan pl{};
+    pl.radixBits = radixBits;
+    if (radixBits <= 8) { pl.bits1 = radixBits; pl.bits2 = 0; }
+    else { pl.bits1 = radixBits / 2; pl.bits2 = radixBits - pl.bits1; }  // prj_thread :814-816
+    const uint64_t n = nR > nS ? nR : nS;
+    const uint32_t F1 = 1u << pl.bits1, F2 = 1u << pl.bits2;
+    const PassLayout l1 = pass_layout(n, 1, F1);
+    const PassLayout l2 = pass_layout(n, F1, F2);
+    pl.maxChunks1 = l1.maxChunks;
+    pl.maxChunks2 = l2.maxChunks;
+    const uint64_t histMax = l1.histEntries > l2.histEntries ? l1.histEntries : l2.histEntries;
+    const uint64_t sumsMax = l1.scanBlocks > l2.scanBlocks ? l1.scanBlocks : l2.scanBlocks;
+    const uint64_t P = (uint64_t)F1 * F2;
+    size_t bytes = 0;
+    bytes += align_up(sizeof(uint32_t) * 2, 256);               // seg0
+    bytes += align_up(sizeof(uint32_t) * (F1 + 1), 256);        // seg1 (after pass 1)
+    bytes += align_up(sizeof(uint32_t) * (F1 + 2), 256);        // chunkBase
+    bytes += align_up(sizeof(uint32_t) * histMax, 256);         // hist / scanned
+    bytes += align_up(sizeof(uint32_t) * (sumsMax + 1), 256);   // block sums
+    bytes += 2 * align_up(sizeof(uint32_t) * (P + 1), 256);     // final offsets R, S
+    pl.workspaceBytes = bytes;
+    return pl;
+}
+
+namespace {
+struct Work {
+    uint32_t *seg0, *seg1, *chunkBase, *hist, *sums, *offR, *offS;
+};
+Work carve(const PrjPlan& pl, void* base, uint64_t n)
+{
+    const uint32_t F1 = 1u << pl.bits1, F2 = 1u << pl.bits2;
+    const PassLayout l1 = pass_layout(n, 1, F1);
+    const PassLayout l2 = pass_layout(n, F1, F2);
+    const uint64_t histMax = l1.histEntries > l2.histEntries ? l1.histEntries : l2.histEntries;
+    const uint64_t sumsMax = l1.scanBlocks > l2.scanBlocks ? l1.scanBlocks : l2.scanBlocks;
+    const uint64_t P = (uint64_t)F1 * F2;
+    char* p = static_cast<char*>(base);
+    Work w;
+    w.seg0 = reinterpret_cast<uint32_t*>(p); p += align_up(sizeof(uint32_t) * 2, 256);
+    w.seg1 = reinterpret_cast<uint32_t*>(p); p += align_up(sizeof(uint32_t) * (F1 + 1), 256);
+    w.chunkBase = reinterpret_cast<uint32_t*>(p); p += align_up(sizeof(uint32_t) * (F1 + 2), 256);
+    w.hist = reinterpret_cast<uint32_t*>(p); p += align_up(sizeof(uint32_t) * histMax, 256);
+    w.sums = reinterpret_cast<uint32_t*>(p); p += align_up(sizeof(uint32_t) * (sumsMax + 1), 256);
+    w.offR = reinterpret_cast<uint32_t*>(p); p += align_up(sizeof(uint32_t) * (P + 1), 256);
+    w.offS = reinterpret_cast<uint32_t*>(p);
+    return w;
+}
+
+// One radix pass: in -> out, segments segIn[nSeg+1] -> segOut[nSeg*fan+1].
+void run_pass(const uint64_t* in, uint64_t* out, uint64_t n, const uint32_t* segIn, uint32_t nSeg,
+              uint32_t shift, uint32_t bits, uint32_t* segOut, const Work& w, hipStream_t s)
+{
+    const uint32_t fan = 1u << bits;
+    const PassLayout l = pass_layout(n, nSeg, fan);
+    hipLaunchKernelGGL(k_chunk_base, dim3(1), dim3(64), 0, s, segIn, nSeg, l.chunkLen, w.chunkBase);
+    PassParams p{segIn, nSeg, l.chunkLen, w.chunkBase, shift, fan};
+    // entries past the live chunks must be zero for the scan to be a prefix of live data only
+    hipMemsetAsync(w.hist, 0, sizeof(uint32_t) * l.histEntries, s);
+    hipLaunchKernelGGL(k_radix_hist, dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s, in, p, w.hist);
+    hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)l.scanBlocks), dim3(kBlock), 0, s, w.hist, l.histEntries, w.sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, s, w.sums, (uint32_t)l.scanBlocks);
+    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)l.scanBlocks), dim3(kBlock), 0, s, w.hist, l.histEntries, w.sums);
+    const uint32_t nOut = nSeg * fan + 1;
+    hipLaunchKernelGGL(k_seg_offsets, dim3((nOut + kBlock - 1) / kBlock), dim3(kBlock), 0, s, p, w.hist, (uint32_t)n, segOut);
+    hipLaunchKernelGGL(k_radix_scatter, dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s, in, out, p, w.hist);
+}
+
+void partition_relation(const PrjPlan& pl, const Work& w, const uint64_t* in, uint64_t n,
+                        uint64_t* tmp, uint64_t* out, uint32_t* finalOff, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_init_seg, dim3(1), dim3(64), 0, s, w.seg0, (uint32_t)n);
+    if (pl.bits2 == 0) {
+        run_pass(in, out, n, w.seg0, 1, 0, pl.bits1, finalOff, w, s);
+    } else {
+        run_pass(in, tmp, n, w.seg0, 1, 0, pl.bits1, w.seg1, w, s);                          // pass 1, R = 0
+        run_pass(tmp, out, n, w.seg1, 1u << pl.bits1, pl.bits1, pl.bits2, finalOff, w, s);    // pass 2, R = bits1
+    }
+}
+}  // namespace
+
+void launch_prj(const PrjPlan& pl, const PrjBuffers& buf, const uint64_t* R, uint64_t nR,
+                const uint64_t* S, uint64_t nS, Counters* ctr, hipEvent_t evPartDone, hipStream_t s)
+{
+    const uint64_t n = nR > nS ? nR : nS;
+    const Work w = carve(pl, buf.work, n);
+    partition_relation(pl, w, R, nR, buf.tmpA, buf.partR, w.offR, s);
+    if (S) partition_relation(pl, w, S, nS, buf.tmpA, buf.partS, w.offS, s);
+    if (evPartDone) hipEventRecord(evPartDone, s);
+    const uint32_t P = 1u << pl.radixBits;
+    static bool attrSet = false;
+    if (!attrSet) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_prj_join),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kJoinSlots * sizeof(uint32_t));
+        attrSet = true;
+    }
+    hipLaunchKernelGGL(k_prj_join, dim3(P), dim3(kJoinThreads), kJoinSlots * sizeof(uint32_t), s,
+                       buf.partR, w.offR, S ? buf.partS : nullptr, w.offS, pl.radixBits, ctr);
+}
+
+}  // namespace hj

@@ -1,0 +1,233 @@
+// main.cpp -- the `main` command line of the reference (main.cpp:21-128), kept
+// flag for flag, in front of libhtmjoin_hip.so. Host C++ only: it sees the C ABI
+// of include/htm_hashjoin.h and no HIP types.
+//
+//   ./main --algo atomic --rSize 134217728 --dataDistr uniform
+//   ./main --algo prj    --rSize 1073741824 --dataDistr local_shuffle --shuffleRange 1024
+//
+// --algo values:
+//   atomic | htm | hip-atomic   open-addressing build+probe on the GPU (the TSX /
+//                               CAS insert loops replaced by the index-priority kernels)
+//   prj | hip-prj | PRO         radix-partitioned join on the GPU
+//   nocc | cpu-atomic           the reference's own loops on host threads
+//                               (NoCCHashBuild.hpp:37-81 / AtomicHashBuild.hpp:37-86):
+//                               the plumbing / CPU-baseline path; never a fallback --
+//                               GPU algos fail if there is no gfx950 device.
+// Defaults are main.cpp:78-85. Unknown flag -> "Found Unknown Arg: X", exit 1
+// (:64-65); unknown algo -> "Unknown Algo: X", exit 0 (:108).
+// Output: one JSON object per run, the reference's fields first and in its order
+// (NoCCHashBuild.hpp:127-146), extra fields appended.
+
+#include "../../include/htm_hashjoin.h"
+
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+struct param_t {  // main.cpp:21-41, plus extensions at the end
+    std::string algo = "htm";
+    uint64_t rSize = 1u << 28;
+    uint32_t transactionSize = 16;
+    uint32_t probeLength = 4;
+    std::string dataDistr = "shuffle";
+    uint32_t shuffleRange = 16;
+    uint32_t scaleOutput = 2;
+    uint32_t numPartitions = 64;
+    // extensions
+    int probe = 1;           // ENABLE_PROBE (config.h:4) as a run-time switch
+    uint64_t sSize = 0;      // 0 = rSize (main.cpp:93)
+    std::string sDistr;      // "" = reference behaviour (sorted, or copy of R for random)
+    double zipfTheta = 0.9;
+    uint32_t radixBits = 0;
+    int device = 0;
+    int repeat = 1;
+};
+
+void parseArgs(int argc, char** argv, param_t* p)
+{
+    for (int i = 1; i < argc; i++) {
+        const char* a = argv[i];
+        const char* v = (i + 1 < argc) ? argv[i + 1] : "";
+        if (strcmp(a, "--algo") == 0) p->algo = v;
+        else if (strcmp(a, "--rSize") == 0) p->rSize = strtoull(v, nullptr, 10);
+        else if (strcmp(a, "--transactionSize") == 0) p->transactionSize = atoi(v);
+        else if (strcmp(a, "--probeLength") == 0) {
+            // main.cpp:53-54 stores this into dataDistr, so the reference always runs
+            // with probeLength 4; accepted and ignored here for script compatibility
+        }
+        else if (strcmp(a, "--dataDistr") == 0) p->dataDistr = v;
+        else if (strcmp(a, "--shuffleRange") == 0) p->shuffleRange = atoi(v);
+        else if (strcmp(a, "--scaleOutput") == 0) p->scaleOutput = atoi(v);
+        else if (strcmp(a, "--numPartitions") == 0) p->numPartitions = atoi(v);
+        else if (strcmp(a, "--probe") == 0) p->probe = atoi(v);
+        else if (strcmp(a, "--sSize") == 0) p->sSize = strtoull(v, nullptr, 10);
+        else if (strcmp(a, "--sDistr") == 0) p->sDistr = v;
+        else if (strcmp(a, "--zipfTheta") == 0) p->zipfTheta = atof(v);
+        else if (strcmp(a, "--radixBits") == 0) p->radixBits = atoi(v);
+        else if (strcmp(a, "--device") == 0) p->device = atoi(v);
+        else if (strcmp(a, "--repeat") == 0) p->repeat = atoi(v);
+        else {
+            std::cout << "Found Unknown Arg: " << a << std::endl;
+            exit(1);
+        }
+        i++;
+    }
+}
+
+double now_us()
+{
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ---- the reference's CPU loops on host threads ------------------------------
+struct cpu_result { uint64_t conflicts = 0, matches = 0, inputSum = 0, outputSum = 0; double us = 0; int threads = 0; };
+
+template <class F>
+void for_chunks(uint32_t chunks, int nthreads, F f)
+{
+    // parallel_for(blocked_range(0, n, n/numPartitions)): <= numPartitions tasks
+    std::atomic<uint32_t> next{0};
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t)
+        th.emplace_back([&] { for (uint32_t c; (c = next.fetch_add(1)) < chunks;) f(c); });
+    for (auto& x : th) x.join();
+}
+
+cpu_result cpu_build_probe(bool useCas, const uint64_t* R, uint64_t rSize, const uint64_t* S, uint64_t sSize,
+                           uint32_t numPartitions, uint32_t probeLength)
+{
+    cpu_result res;
+    const uint64_t tableSize = rSize * 2, mask = tableSize - 1;
+    std::vector<std::atomic<uint64_t>> output(tableSize + 4);
+    for (auto& s : output) s.store(0, std::memory_order_relaxed);
+    std::vector<uint64_t> conf(numPartitions, 0), confSum(numPartitions, 0), match(numPartitions, 0);
+    int nthreads = (int)std::min<unsigned>(numPartitions, std::max(1u, std::thread::hardware_concurrency()));
+    res.threads = nthreads;
+    const double t0 = now_us();
+    for_chunks(numPartitions, nthreads, [&](uint32_t c) {
+        const uint64_t ps = rSize / numPartitions, b = c * ps, e = (c + 1 == numPartitions) ? rSize : b + ps;
+        for (uint64_t i = b; i < e; ++i) {
+            uint64_t cur = R[i] & mask;
+            uint32_t budget = probeLength;
+            while (budget != 0) {
+                const uint64_t prev = output[cur].load(std::memory_order_relaxed);
+                if (prev == 0) {
+                    if (!useCas) { output[cur].store(R[i], std::memory_order_relaxed); break; }
+                    uint64_t zero = 0;
+                    if (output[cur].compare_exchange_strong(zero, R[i])) break;
+                    budget--;  // AtomicHashBuild.hpp:54
+                } else { cur = (cur + 1) & mask; budget--; }
+            }
+            if (budget == 0) { conf[c]++; confSum[c] += R[i]; }
+        }
+    });
+    if (S)
+        for_chunks(numPartitions, nthreads, [&](uint32_t c) {
+            const uint64_t ps = sSize / numPartitions, b = c * ps, e = (c + 1 == numPartitions) ? sSize : b + ps;
+            uint64_t m = 0;
+            for (uint64_t i = b; i < e; ++i) {
+                uint64_t cur = S[i] & mask;
+                uint32_t budget = probeLength;
+                while (budget-- && output[cur].load(std::memory_order_relaxed) != 0) {
+                    if (output[cur].load(std::memory_order_relaxed) == S[i]) m++;
+                    cur++;
+                }
+            }
+            match[c] = m;
+        });
+    res.us = now_us() - t0;
+    for (uint64_t i = 0; i < rSize; ++i) res.inputSum += R[i];
+    const uint64_t upto = useCas ? tableSize : rSize;  // NoCCHashBuild.hpp:94 vs AtomicHashBuild.hpp:100
+    for (uint64_t i = 0; i < upto; ++i) res.outputSum += output[i].load(std::memory_order_relaxed);
+    for (uint32_t c = 0; c < numPartitions; ++c) { res.conflicts += conf[c]; res.outputSum += confSum[c]; res.matches += match[c]; }
+    return res;
+}
+
+}  // namespace
+
+int main(int argc, char* argv[])
+{
+    param_t p;
+    parseArgs(argc, argv, &p);
+
+    const bool gpuOA = p.algo == "atomic" || p.algo == "htm" || p.algo == "hip-atomic";
+    const bool gpuPRJ = p.algo == "prj" || p.algo == "hip-prj" || p.algo == "PRO";
+    const bool cpu = p.algo == "nocc" || p.algo == "cpu-atomic";
+    if (!gpuOA && !gpuPRJ && !cpu) {
+        std::cout << "Unknown Algo: " << p.algo << std::endl;  // main.cpp:108
+        return 0;
+    }
+
+    const uint64_t sSize = p.sSize ? p.sSize : p.rSize;
+    std::vector<uint64_t> relR(p.rSize), relS;
+    if (hj_generate_data(p.dataDistr.c_str(), p.rSize, p.rSize, (int)p.shuffleRange, p.zipfTheta, relR.data()) != HJ_OK) {
+        std::cout << "Unknown distribution" << std::endl;  // DataGen.hpp:117-118
+        return 1;
+    }
+    if (p.probe) {
+        relS.resize(sSize);
+        if (!p.sDistr.empty()) {
+            if (hj_generate_data(p.sDistr.c_str(), sSize, p.rSize, (int)p.shuffleRange, p.zipfTheta, relS.data()) != HJ_OK) {
+                std::cout << "Unknown distribution" << std::endl;
+                return 1;
+            }
+        } else if (p.dataDistr != "random") {  // main.cpp:92-97
+            hj_generate_data("sorted", sSize, p.rSize, (int)p.shuffleRange, 0, relS.data());
+        } else {
+            for (uint64_t i = 0; i < sSize; ++i) relS[i] = relR[i % p.rSize];
+        }
+    }
+    const uint64_t* S = p.probe ? relS.data() : nullptr;
+
+    for (int rep = 0; rep < p.repeat; ++rep) {
+        if (cpu) {
+            const cpu_result r = cpu_build_probe(p.algo == "cpu-atomic", relR.data(), p.rSize, S, sSize, p.numPartitions, p.probeLength);
+            std::cout << "{\"algo\": \"" << (p.algo == "nocc" ? "nocc" : "atomic") << "\",\"rSize\": " << p.rSize
+                      << ", \"probeLength\": " << p.probeLength << ", \"hashBuildTimeInMicroseconds\": " << (uint64_t)r.us
+                      << ", \"conflicts\": " << r.conflicts;
+            if (p.probe) std::cout << ", \"totalMatches\": " << r.matches;
+            std::cout << ", \"inputSum\": " << r.inputSum << ", \"outputSum\": " << r.outputSum
+                      << ", \"device\": \"cpu\", \"cpu_threads\": " << r.threads << "}" << std::endl;
+            continue;
+        }
+        hj_ctx* ctx = nullptr;
+        int rc = hj_create(p.device, &ctx);
+        if (rc != HJ_OK) {
+            std::cerr << "hj_create: " << hj_strerror(rc) << std::endl;
+            return 2;
+        }
+        hj_params hp{};
+        hp.algo = gpuPRJ ? HJ_ALGO_PRJ : (p.algo == "htm" ? HJ_ALGO_HTM : HJ_ALGO_ATOMIC);
+        hp.scaleOutput = p.scaleOutput; hp.numPartitions = p.numPartitions; hp.probeLength = p.probeLength;
+        hp.transactionSize = p.transactionSize; hp.radixBits = p.radixBits;
+        hj_result r{};
+        rc = hj_run(ctx, &hp, relR.data(), p.rSize, S, S ? sSize : 0, &r);
+        if (rc != HJ_OK) {
+            std::cerr << "hj_run: " << hj_strerror(rc) << " (" << hj_last_error(ctx) << ")" << std::endl;
+            hj_destroy(ctx);
+            return 2;
+        }
+        const double mt = (double)(p.rSize + (S ? sSize : 0)) / r.total_us;
+        std::cout << "{\"algo\": \"" << p.algo << "\",\"rSize\": " << p.rSize;
+        if (p.algo == "htm") std::cout << ", \"transactionSize\": " << p.transactionSize;
+        std::cout << ", \"probeLength\": " << p.probeLength << ", \"hashBuildTimeInMicroseconds\": " << (uint64_t)r.total_us;
+        if (!gpuPRJ) std::cout << ", \"conflicts\": " << r.conflicts;
+        if (p.probe) std::cout << ", \"totalMatches\": " << r.totalMatches;
+        if (gpuPRJ) std::cout << ", \"results\": " << r.prjChecksum << ", \"radixBits\": " << r.radixBits;
+        else std::cout << ", \"inputSum\": " << r.inputSum << ", \"outputSum\": " << r.outputSum;
+        std::cout << ", \"device\": \"hip\", \"sSize\": " << (S ? sSize : 0) << ", \"mtuples_per_s\": " << mt
+                  << ", \"clear_us\": " << r.clear_us << ", \"build_us\": " << r.build_us << ", \"probe_us\": " << r.probe_us
+                  << ", \"partition_us\": " << r.partition_us << ", \"join_us\": " << r.join_us
+                  << ", \"h2d_us\": " << r.h2d_us << "}" << std::endl;
+        hj_destroy(ctx);
+    }
+    return 0;
+}

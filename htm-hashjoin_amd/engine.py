@@ -1,0 +1,192 @@
+"""Host-side mirror of the reference's operator interface.
+
+    reference (C++)                                   here
+    ------------------------------------------------  ---------------------------------
+    generate_data(dist, n, distinct, window)          generate_data(...)      DataGen.hpp:26
+    NoCCHashBuild(relR,rSize,relS,sSize,scale,P,pl)    NoCCHashBuild(...)      NoCCHashBuild.hpp:13
+    AtomicHashBuild(... same ...)                      AtomicHashBuild(...)    AtomicHashBuild.hpp:14
+    HTMHashBuild(relR,rSize,relS,sSize,tSize,...)      HTMHashBuild(...)       HTMHashBuild.hpp:54
+    PRO(relR, relS, nthreads)                          PRO(...)                mc/src/parallel_radix_join.c:1305
+
+The reference functions return void and print one JSON line; these return the
+same fields as a dict. Every operator runs on the GPU through the C ABI; without
+a gfx950 device they raise HashJoinError(HJ_ERR_NO_DEVICE).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, hj_params, hj_result
+
+
+class HashJoinError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        msg = lib.hj_strerror(status).decode()
+        super().__init__(f"{msg} [{status}]" + (f": {detail}" if detail else ""))
+
+
+def device_count():
+    n = C.c_int(0)
+    lib.hj_device_count(C.byref(n))
+    return n.value
+
+
+def generate_data(dist, size_in_tuples, distinct_keys=None, local_shuffle_range=16, zipf_theta=0.9):
+    """include/DataGen.hpp:26 -- returns a numpy uint64 array of size_in_tuples tuples."""
+    if distinct_keys is None:
+        distinct_keys = size_in_tuples
+    out = np.empty(size_in_tuples, dtype=np.uint64)
+    rc = lib.hj_generate_data(dist.encode(), size_in_tuples, distinct_keys, int(local_shuffle_range),
+                              float(zipf_theta), out.ctypes.data)
+    if rc != _lib.HJ_OK:
+        raise HashJoinError(rc, f"Unknown distribution {dist!r}")
+    return out
+
+
+def _params(algo, scaleOutput=2, numPartitions=64, probeLength=4, transactionSize=16, radixBits=0):
+    p = hj_params()
+    p.algo = _lib.ALGO_IDS[algo]
+    p.scaleOutput, p.numPartitions, p.probeLength = scaleOutput, numPartitions, probeLength
+    p.transactionSize, p.radixBits = transactionSize, radixBits
+    return p
+
+
+class HashJoinContext:
+    """One engine context bound to one GPU (hj_ctx). ``stream`` is a raw hipStream_t
+    handle (e.g. torch.cuda.current_stream().cuda_stream); None = private stream."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p()
+        if stream is None:
+            rc = lib.hj_create(device, C.byref(self._h))
+        else:
+            rc = lib.hj_create_on_stream(device, C.c_void_p(stream), C.byref(self._h))
+        if rc != _lib.HJ_OK:
+            self._h = None
+            raise HashJoinError(rc)
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.hj_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        if rc != _lib.HJ_OK:
+            raise HashJoinError(rc, lib.hj_last_error(self._h).decode())
+
+    # ---- one-shot, host buffers -------------------------------------------
+    def run(self, algo, relR, relS=None, **kw):
+        relR = np.ascontiguousarray(relR, dtype=np.uint64)
+        if relS is not None:
+            relS = np.ascontiguousarray(relS, dtype=np.uint64)
+        p = _params(algo, **kw)
+        r = hj_result()
+        self._check(lib.hj_run(self._h, C.byref(p), relR.ctypes.data, relR.size,
+                               relS.ctypes.data if relS is not None else None,
+                               relS.size if relS is not None else 0, C.byref(r)))
+        return r.as_dict()
+
+    # ---- split API, device pointers ---------------------------------------
+    def reserve(self, algo, rSize, sSize, **kw):
+        p = _params(algo, **kw)
+        self._check(lib.hj_reserve(self._h, C.byref(p), rSize, sSize))
+
+    def build(self, dR_ptr, rSize, idx_base=0):
+        self._check(lib.hj_build_dev(self._h, C.c_void_p(dR_ptr), rSize, idx_base))
+
+    def probe(self, dS_ptr, sSize):
+        self._check(lib.hj_probe_dev(self._h, C.c_void_p(dS_ptr), sSize))
+
+    def prj_join(self, dR_ptr, rSize, dS_ptr, sSize):
+        self._check(lib.hj_prj_join_dev(self._h, C.c_void_p(dR_ptr), rSize,
+                                        C.c_void_p(dS_ptr) if dS_ptr else None, sSize))
+
+    def checksums(self):
+        self._check(lib.hj_checksums_dev(self._h))
+
+    def fetch(self):
+        r = hj_result()
+        self._check(lib.hj_fetch_result(self._h, C.byref(r)))
+        return r.as_dict()
+
+    def synchronize(self):
+        self._check(lib.hj_synchronize(self._h))
+
+    def export_table(self, tableSize):
+        out = np.empty(tableSize, dtype=np.uint64)
+        self._check(lib.hj_export_table(self._h, out.ctypes.data, tableSize))
+        return out
+
+    def shard_histogram(self, d_in, n, n_shards, mode, table_size, d_counts):
+        self._check(lib.hj_shard_histogram_dev(self._h, C.c_void_p(d_in), n, n_shards, mode, table_size,
+                                               C.c_void_p(d_counts)))
+
+    def shard_scatter(self, d_in, n, n_shards, mode, table_size, d_counts, pack_idx_base, d_out):
+        base = 0xFFFFFFFFFFFFFFFF if pack_idx_base is None else pack_idx_base
+        self._check(lib.hj_shard_scatter_dev(self._h, C.c_void_p(d_in), n, n_shards, mode, table_size,
+                                             C.c_void_p(d_counts), base, C.c_void_p(d_out)))
+
+    def build_packed(self, d_packed, n, global_table_size, slot_base, slice_slots):
+        self._check(lib.hj_build_packed_dev(self._h, C.c_void_p(d_packed), n, global_table_size,
+                                            slot_base, slice_slots))
+
+
+def _operator(algo, relR, rSize, relS, sSize, device, **kw):
+    relR = np.asarray(relR, dtype=np.uint64)[:rSize]
+    if relS is not None:
+        relS = np.asarray(relS, dtype=np.uint64)[:sSize]
+    with HashJoinContext(device) as ctx:
+        r = ctx.run(algo, relR, relS, **kw)
+    out = {"algo": algo, "rSize": r["rSize"], "probeLength": kw.get("probeLength", 4),
+           "hashBuildTimeInMicroseconds": int(r["total_us"]), "conflicts": r["conflicts"]}
+    if relS is not None:
+        out["totalMatches"] = r["totalMatches"]
+    out["inputSum"] = r["inputSum"]
+    out["outputSum"] = r["outputSum"]
+    out["detail"] = r
+    return out
+
+
+def NoCCHashBuild(relR, rSize, relS=None, sSize=0, scaleOutput=2, numPartitions=64, probeLength=4, device=0):
+    """NoCCHashBuild.hpp:13-19. outputSum keeps the [0, rSize) quirk of :94."""
+    return _operator("nocc", relR, rSize, relS, sSize, device, scaleOutput=scaleOutput,
+                     numPartitions=numPartitions, probeLength=probeLength)
+
+
+def AtomicHashBuild(relR, rSize, relS=None, sSize=0, scaleOutput=2, numPartitions=64, probeLength=4, device=0):
+    """AtomicHashBuild.hpp:14-20."""
+    return _operator("atomic", relR, rSize, relS, sSize, device, scaleOutput=scaleOutput,
+                     numPartitions=numPartitions, probeLength=probeLength)
+
+
+def HTMHashBuild(relR, rSize, relS=None, sSize=0, transactionSize=16, scaleOutput=2, numPartitions=64,
+                 probeLength=4, device=0):
+    """HTMHashBuild.hpp:54-60. The TSX transaction groups are replaced outright by the
+    index-priority kernels; transactionSize is accepted and echoed."""
+    out = _operator("htm", relR, rSize, relS, sSize, device, scaleOutput=scaleOutput,
+                    numPartitions=numPartitions, probeLength=probeLength, transactionSize=transactionSize)
+    out["transactionSize"] = transactionSize
+    return out
+
+
+def PRO(relR, relS=None, nthreads=0, radixBits=0, device=0):
+    """mc/src/parallel_radix_join.c:1305 (algos[] entry, mc/src/main.c:292-301).
+    Returns the join cardinality and the fork's printed checksum ("Results")."""
+    relR = np.asarray(relR, dtype=np.uint64)
+    if relS is not None:
+        relS = np.asarray(relS, dtype=np.uint64)
+    with HashJoinContext(device) as ctx:
+        r = ctx.run("prj", relR, relS, radixBits=radixBits)
+    return {"algo": "PRO", "matches": r["totalMatches"], "results": r["prjChecksum"],
+            "radixBits": r["radixBits"], "detail": r}

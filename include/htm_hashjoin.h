@@ -1,0 +1,194 @@
+/*
+ * htm_hashjoin.h -- C ABI of libhtmjoin_hip.so, the MI355X (gfx950) hash-join
+ * build+probe engine.
+ *
+ * This is the drop-in boundary for the hot path of anilshanbhag/HTM-HashJoin.
+ * The reference has no FFI layer: its operator interface is a set of C++ free
+ * functions picked by a string compare in main (main.cpp:99-108 with probe,
+ * :115-122 build only), plus mc's function-pointer table
+ * (mc/src/main.c:262-301).  Each entry point below names the reference
+ * interface it replaces.  Plain pointers and sizes only; no HIP, torch or C++
+ * types cross this boundary.  INTEGRATION.md shows the reference-side binding.
+ *
+ * Tuple layout (A0): one uint64_t per tuple whose value is the key; seen as
+ * little-endian {uint32 key; uint32 payload=0} it is mc's tuple_t
+ * (include/DataGen.hpp:29, mc/src/types.h:34-37).
+ *
+ * Error behaviour: the reference returns void and exits on allocation failure
+ * (HTMHashBuild.hpp:66-70, mc MALLOC_CHECK).  This library never exits: every
+ * call returns HJ_OK (0) or a negative hj_status; hj_last_error() gives text.
+ * There is NO CPU fallback: without a usable gfx950 device hj_create fails
+ * with HJ_ERR_NO_DEVICE.
+ */
+#ifndef HTM_HASHJOIN_H
+#define HTM_HASHJOIN_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HJ_ABI_VERSION 1
+
+typedef enum {
+    HJ_OK                  = 0,
+    HJ_ERR_INVALID         = -1,  /* bad argument / unsupported size           */
+    HJ_ERR_NO_DEVICE       = -2,  /* no HIP device / not gfx950                */
+    HJ_ERR_HIP             = -3,  /* a HIP runtime call failed                 */
+    HJ_ERR_OOM             = -4,  /* device allocation failed                  */
+    HJ_ERR_KEY_RANGE       = -5,  /* a tuple has non-zero payload bits or is 0 */
+    HJ_ERR_UNKNOWN_ALGO    = -6,
+    HJ_ERR_STATE           = -7   /* call order violated (e.g. probe w/o build)*/
+} hj_status;
+
+/* Which reference operator the call stands in for. All of NOCC/ATOMIC/HTM run
+ * the same order-deterministic open-addressing kernels (Intel TSX and the racy
+ * store are replaced outright); they differ only in the reported name and in
+ * which checksum quirk outputSum follows (see hj_result). */
+typedef enum {
+    HJ_ALGO_NOCC   = 0,  /* NoCCHashBuild   (NoCCHashBuild.hpp:13-151)   */
+    HJ_ALGO_ATOMIC = 1,  /* AtomicHashBuild (AtomicHashBuild.hpp:14-157) */
+    HJ_ALGO_HTM    = 2,  /* HTMHashBuild    (HTMHashBuild.hpp:54-464)    */
+    HJ_ALGO_PRJ    = 3   /* mc PRO          (mc/src/parallel_radix_join.c:1305) */
+} hj_algo;
+
+/* Mirrors the trailing arguments of the reference signatures
+ * (NoCCHashBuild.hpp:13-19; HTMHashBuild.hpp:54-60) and mc's compile-time
+ * NUM_RADIX_BITS (mc/src/prj_params.h:16). Zero means "reference default". */
+typedef struct {
+    uint32_t algo;            /* hj_algo                                        */
+    uint32_t scaleOutput;     /* accepted, unused: tableSize is 2*rSize
+                                 (main.cpp:59-60, NoCCHashBuild.hpp:20)         */
+    uint32_t numPartitions;   /* default 64 (main.cpp:84); informational        */
+    uint32_t probeLength;     /* default 4  (main.cpp:80)                       */
+    uint32_t transactionSize; /* default 16 (main.cpp:82); echoed for htm       */
+    uint32_t radixBits;       /* PRJ only. 0 = auto (>= 14 so that every
+                                 R partition fits one LDS table)                */
+    uint32_t buildVariant;    /* 0 = auto; 1 = global atomicMin kernel;
+                                 2 = LDS-window ownership kernel                */
+    uint32_t reserved[5];
+} hj_params;
+
+/* Everything the reference prints in its JSON line (NoCCHashBuild.hpp:127-146,
+ * AtomicHashBuild.hpp:133-152) plus device timings. */
+typedef struct {
+    uint64_t rSize, sSize, tableSize;
+    uint64_t conflicts;       /* tuples that exhausted probeLength ("conflicts") */
+    uint64_t totalMatches;
+    uint64_t inputSum;        /* sum of R                                        */
+    uint64_t tableSumHalf;    /* sum of table[0..rSize)                          */
+    uint64_t tableSumFull;    /* sum of table[0..tableSize)                      */
+    uint64_t conflictSum;     /* sum of dropped keys                             */
+    uint64_t outputSum;       /* nocc:  tableSumHalf + conflictSum (the
+                                 NoCCHashBuild.hpp:94 quirk, kept for log parity);
+                                 atomic/htm: tableSumFull + conflictSum           */
+    uint64_t prjChecksum;     /* PRJ: sum of bucket idx == mc PRO "Results"
+                                 (parallel_radix_join.c:256) when radixBits=14    */
+    uint64_t prjPartitions;   /* PRJ: number of final partitions                  */
+    uint32_t radixBits;       /* PRJ: bits actually used                          */
+    uint32_t buildVariant;    /* kernel actually used                             */
+    /* device time of the last call of each phase, from HIP events on the
+     * context's stream, in microseconds */
+    double clear_us, build_us, probe_us, partition_us, join_us, total_us;
+    double h2d_us;            /* hj_run only: host->device copies (reported
+                                 separately, never part of total_us)              */
+    uint64_t reserved[4];
+} hj_result;
+
+typedef struct hj_ctx hj_ctx;
+
+/* ---- context ------------------------------------------------------------- */
+int  hj_abi_version(void);
+int  hj_device_count(int *count);
+/* Binds to `device`, checks it is gfx950, creates a private stream. */
+int  hj_create(int device, hj_ctx **out);
+/* Same, but launches on the caller's stream (a hipStream_t passed as void*;
+ * NULL = the default stream). Lets a host that owns streams (PyTorch) time and
+ * order the kernels itself. */
+int  hj_create_on_stream(int device, void *hip_stream, hj_ctx **out);
+void hj_destroy(hj_ctx *ctx);
+const char *hj_strerror(int status);
+const char *hj_last_error(const hj_ctx *ctx);
+int  hj_synchronize(hj_ctx *ctx);
+
+/* ---- one-shot operator, host buffers ------------------------------------- */
+/* Replaces NoCCHashBuild/AtomicHashBuild/HTMHashBuild(relR, rSize, relS, sSize,
+ * ...) as called at main.cpp:99-104, and mc's PRO(relR, relS, nthreads)
+ * (mc/src/main.c:292-301) for HJ_ALGO_PRJ. relS may be NULL / sSize 0 for the
+ * build-only variant (main.cpp:115-120, ENABLE_PROBE 0). Inputs are read-only
+ * and stay host-owned; device memory is owned by ctx. Like the reference
+ * (NoCCHashBuild.hpp:24-34) allocation, host->device copies and checksums are
+ * outside total_us. */
+int hj_run(hj_ctx *ctx, const hj_params *params,
+           const uint64_t *relR, uint64_t rSize,
+           const uint64_t *relS, uint64_t sSize, hj_result *out);
+
+/* ---- split operator, device-resident buffers ------------------------------ */
+/* Allocate the table / partition workspace for these sizes (the `new[]` block
+ * of NoCCHashBuild.hpp:24-31). Idempotent; grows only. */
+int hj_reserve(hj_ctx *ctx, const hj_params *params, uint64_t rSize, uint64_t sSize);
+/* HOT LOOP 1 (NoCCHashBuild.hpp:37-62 / AtomicHashBuild.hpp:37-67): clears the
+ * table and inserts dR[0..rSize). Asynchronous on the context's stream.
+ * idxBase = global index of dR[0] (0 unless R is a shard of a larger input). */
+int hj_build_dev(hj_ctx *ctx, const uint64_t *dR, uint64_t rSize, uint64_t idxBase);
+/* HOT LOOP 2 (NoCCHashBuild.hpp:66-80): probes dS[0..sSize) against the table
+ * of the last hj_build_dev and accumulates totalMatches. Asynchronous. */
+int hj_probe_dev(hj_ctx *ctx, const uint64_t *dS, uint64_t sSize);
+/* PRJ (parallel_radix_join.c:808-1122): radix-partitions dR and dS and joins
+ * each partition pair in LDS. Asynchronous. dS may be NULL (fork behaviour:
+ * R-side only, checksum only). */
+int hj_prj_join_dev(hj_ctx *ctx, const uint64_t *dR, uint64_t rSize,
+                    const uint64_t *dS, uint64_t sSize);
+/* The untimed reductions of NoCCHashBuild.hpp:85-113 (table sums). Async. */
+int hj_checksums_dev(hj_ctx *ctx);
+/* Waits for the stream and returns counters + timings of the calls above. */
+int hj_fetch_result(hj_ctx *ctx, hj_result *out);
+/* Copies the open-addressing table to host in the reference's format
+ * (tableSize slots, value = key, 0 = empty). */
+int hj_export_table(hj_ctx *ctx, uint64_t *host_table, uint64_t tableSize);
+
+/* ---- multi-GPU sharding helpers (new design) ---------------- */
+/* dest(key) for `nShards` ranks. mode 0 = radix: low bits of the key
+ * (HASH_BIT_MODULO, parallel_radix_join.c:59); mode 1 = range: high bits of the
+ * home slot key&(tableSize-1), which keeps linear-probe neighbours together. */
+/* Counts tuples per destination: dCounts[nShards] (device, uint64). Async. */
+int hj_shard_histogram_dev(hj_ctx *ctx, const uint64_t *dIn, uint64_t n,
+                           uint32_t nShards, uint32_t mode, uint64_t tableSize,
+                           uint64_t *dCounts);
+/* Stable-by-destination scatter of dIn into dOut (both n tuples) using the
+ * exclusive prefix of dCounts as bases. If packIdxBase != UINT64_MAX each
+ * output tuple is (globalIdx << 32 | key) with globalIdx = packIdxBase + i, so
+ * that index priority survives the exchange. Async. */
+int hj_shard_scatter_dev(hj_ctx *ctx, const uint64_t *dIn, uint64_t n,
+                         uint32_t nShards, uint32_t mode, uint64_t tableSize,
+                         const uint64_t *dCounts, uint64_t packIdxBase,
+                         uint64_t *dOut);
+/* Like hj_build_dev but the tuples are already (globalIdx << 32 | key) and the
+ * table is the slice [slotBase, slotBase+sliceSlots) of a global table of
+ * globalTableSize slots. */
+int hj_build_packed_dev(hj_ctx *ctx, const uint64_t *dPacked, uint64_t n,
+                        uint64_t globalTableSize, uint64_t slotBase,
+                        uint64_t sliceSlots);
+
+/* ---- device memory for hosts without a HIP runtime of their own ----------- */
+int hj_dev_alloc(hj_ctx *ctx, uint64_t bytes, void **dptr);
+int hj_dev_free(hj_ctx *ctx, void *dptr);
+int hj_copy_h2d(hj_ctx *ctx, void *dst_dev, const void *src_host, uint64_t bytes);
+int hj_copy_d2h(hj_ctx *ctx, void *dst_host, const void *src_dev, uint64_t bytes);
+
+/* ---- input layer ---------------------------------------------------------- */
+/* generate_data(dist, n, distinct, window) of include/DataGen.hpp:26-122 into a
+ * caller-owned host buffer: same glibc rand() stream after srand(0), same
+ * distributions ("uniform","random","sorted","shuffle","local_shuffle").
+ * "zipf" (an empty stub in the reference, :72-77) draws keys over [1,distinct]
+ * with the LUT method of mc/src/genzipf.c:60-158, theta = zipfTheta.
+ * Returns HJ_ERR_INVALID for an unknown distribution (the reference exits). */
+int hj_generate_data(const char *dist, uint64_t n, uint64_t distinct, int window,
+                     double zipfTheta, uint64_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HTM_HASHJOIN_H */

@@ -1,0 +1,70 @@
+"""The C-ABI library loads and exports every symbol include/htm_hashjoin.h declares.
+No compute calls here (no GPU in this container)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+import htm_hashjoin_amd as hj
+from htm_hashjoin_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "htm_hashjoin.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hj_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    syms = _declared_symbols()
+    assert len(syms) >= 20
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), f"{s} declared in include/htm_hashjoin.h but not exported"
+        assert s in hj.lib._hj_signatures, f"{s} has no ctypes signature in _lib.py"
+
+
+def test_no_undeclared_exports():
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("hj_")}
+    assert exported == set(_declared_symbols())
+
+
+def test_struct_layouts_match_header():
+    assert ctypes.sizeof(_lib.hj_params) == 12 * 4
+    assert ctypes.sizeof(_lib.hj_result) == 12 * 8 + 2 * 4 + 7 * 8 + 4 * 8
+
+
+def test_abi_version_and_strerror():
+    assert hj.lib.hj_abi_version() == 1
+    assert b"no gfx950" in hj.lib.hj_strerror(_lib.HJ_ERR_NO_DEVICE)
+    assert hj.lib.hj_strerror(0) == b"ok"
+
+
+@pytest.mark.skipif(hj.device_count() > 0, reason="checks the no-GPU failure mode")
+def test_operators_fail_loudly_without_a_gpu():
+    with pytest.raises(hj.HashJoinError) as e:
+        hj.HashJoinContext(0)
+    assert e.value.status == _lib.HJ_ERR_NO_DEVICE
+    R = hj.generate_data("sorted", 64)
+    for op in (hj.NoCCHashBuild, hj.AtomicHashBuild, hj.HTMHashBuild):
+        with pytest.raises(hj.HashJoinError):
+            op(R, 64, R, 64)
+    with pytest.raises(hj.HashJoinError):
+        hj.PRO(R, R)
+
+
+def test_product_does_not_reference_the_oracle():
+    """The product tree must not import, include or link anything under oracle/."""
+    pkg = os.path.join(ROOT, "htm-hashjoin_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in text.lower(), os.path.join(dirpath, f)
+    out = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out

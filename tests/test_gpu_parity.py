@@ -1,0 +1,196 @@
+"""Parity tests proper: the HIP engine, called through the C ABI, against the CPU
+oracle on identical inputs. Bit-exact (integer work). Run with -m gpu on an MI355X."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import htm_hashjoin_amd as hj
+from htm_hashjoin_amd import _lib
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = hj.HashJoinContext(0)
+    yield c
+    c.close()
+
+
+def check_oa(got, want, algo="atomic"):
+    for k in ("conflicts", "totalMatches", "inputSum", "tableSumHalf", "tableSumFull", "conflictSum"):
+        assert got[k] == want[k], (k, got[k], want[k])
+    assert got["outputSum"] == (want["outputSumNocc"] if algo == "nocc" else want["outputSumAtomic"])
+
+
+DISTS = [("uniform", 16), ("uniform", 2), ("random", 16), ("sorted", 16), ("shuffle", 16),
+         ("local_shuffle", 16), ("local_shuffle", 1024)]
+
+
+@pytest.mark.parametrize("dist,window", DISTS)
+@pytest.mark.parametrize("n", [1 << 10, 1 << 16, 1 << 20])
+def test_build_probe_matches_sequential_oracle(ctx, dist, window, n):
+    R = oracle.generate_data(dist, n, n, window)
+    S = oracle.relS_for(dist, R)
+    want = oracle.build_probe_seq(R, S, 4, want_table=True)
+    got = ctx.run("atomic", R, S)
+    check_oa(got, want)
+    # the whole table, slot for slot, equals the table a single thread builds in input order
+    assert np.array_equal(ctx.export_table(2 * n), want["table"])
+
+
+def test_golden_appendix_b_through_c_abi(ctx, golden_dir):
+    rows = json.load(open(os.path.join(golden_dir, "survey_appendix.json")))["appendix_b"]
+    for row in rows:
+        R = hj.generate_data(row["dist"], row["rSize"], row["rSize"], row["window"])
+        S = R.copy() if row["dist"] == "random" else hj.generate_data("sorted", row["rSize"])
+        for algo, key in (("nocc", "outputSumNocc"), ("atomic", "outputSumAtomic")):
+            got = ctx.run(algo, R, S)
+            assert (got["conflicts"], got["totalMatches"], got["inputSum"]) == (
+                row["conflicts"], row["totalMatches"], row["inputSum"]), (row, got)
+            if key in row:
+                assert got["outputSum"] == row[key], (row, algo, got["outputSum"])
+
+
+@pytest.mark.parametrize("probe_length", [1, 2, 3, 5, 8])
+def test_other_probe_lengths(ctx, probe_length):
+    n = 1 << 14
+    R = oracle.generate_data("uniform", n, n, 16)
+    S = oracle.generate_data("sorted", n)
+    want = oracle.build_probe_seq(R, S, probe_length, want_table=True)
+    got = ctx.run("atomic", R, S, probeLength=probe_length)
+    check_oa(got, want)
+    assert np.array_equal(ctx.export_table(2 * n), want["table"])
+
+
+def test_heavy_duplicates_and_tiny_sizes(ctx):
+    rng = np.random.default_rng(7)
+    for n, hi in ((1, 2), (2, 3), (4, 3), (64, 5), (1 << 12, 17), (1 << 15, 1 << 10)):
+        R = rng.integers(1, hi, size=n, dtype=np.uint64)
+        S = rng.integers(1, hi + 3, size=3 * n + 1, dtype=np.uint64)   # |S| != |R|, odd length
+        want = oracle.build_probe_seq(R, S, 4, want_table=True)
+        got = ctx.run("atomic", R, S)
+        check_oa(got, want)
+        assert np.array_equal(ctx.export_table(2 * n), want["table"])
+
+
+def test_wraparound_at_table_end(ctx):
+    n = 1 << 10
+    # keys whose home slots are the last slots of the 2n-slot table: probing must wrap (:52)
+    R = np.full(n, 2 * n - 1, dtype=np.uint64)
+    R[::3] = 2 * n - 2
+    S = np.array([2 * n - 1, 2 * n - 2, 1, 2, 4 * n - 1], dtype=np.uint64)
+    want = oracle.build_probe_seq(R, S, 4, want_table=True)
+    got = ctx.run("atomic", R, S)
+    check_oa(got, want)
+    assert np.array_equal(ctx.export_table(2 * n), want["table"])
+
+
+def test_build_only_and_empty_probe(ctx):
+    n = 1 << 12
+    R = oracle.generate_data("uniform", n, n, 16)
+    want = oracle.build_probe_seq(R, None, 4)
+    got = ctx.run("htm", R, None)
+    check_oa(got, want)
+    assert got["totalMatches"] == 0 and got["sSize"] == 0
+
+
+def test_rejects_non_datagen_tuples(ctx):
+    R = np.arange(1, 1025, dtype=np.uint64)
+    bad = R.copy(); bad[17] |= np.uint64(1) << np.uint64(40)          # payload bits set
+    with pytest.raises(hj.HashJoinError) as e:
+        ctx.run("atomic", bad, R)
+    assert e.value.status == _lib.HJ_ERR_KEY_RANGE
+    zero = R.copy(); zero[5] = 0                                       # 0 is the empty marker (:48)
+    with pytest.raises(hj.HashJoinError):
+        ctx.run("atomic", zero, R)
+    with pytest.raises(hj.HashJoinError) as e:                         # rSize must be a power of two
+        ctx.run("atomic", R[:1000], R)
+    assert e.value.status == _lib.HJ_ERR_INVALID
+
+
+def test_operator_mirrors(ctx):
+    n = 1 << 16
+    R = hj.generate_data("local_shuffle", n, n, 1024)
+    S = hj.generate_data("sorted", n)
+    tri = n * (n + 1) // 2
+    j = hj.NoCCHashBuild(R, n, S, n, 2, 64, 4)
+    assert (j["conflicts"], j["totalMatches"], j["inputSum"], j["outputSum"]) == (0, n, tri, tri - n)
+    j = hj.AtomicHashBuild(R, n, S, n, 2, 64, 4)
+    assert (j["conflicts"], j["totalMatches"], j["inputSum"], j["outputSum"]) == (0, n, tri, tri)
+    j = hj.HTMHashBuild(R, n, S, n, 16, 2, 64, 4)
+    assert j["transactionSize"] == 16 and j["totalMatches"] == n
+    j = hj.PRO(R, S)
+    assert j["matches"] == n
+
+
+# ---- PRJ ---------------------------------------------------------------------
+@pytest.mark.parametrize("dist,window", [("uniform", 16), ("random", 16), ("shuffle", 16), ("local_shuffle", 1024)])
+@pytest.mark.parametrize("n,bits", [(1 << 10, 4), (1 << 16, 14), (1 << 20, 14), (1 << 20, 9), (1 << 20, 16)])
+def test_prj_matches_oracle(ctx, dist, window, n, bits):
+    R = oracle.generate_data(dist, n, n, window)
+    S = oracle.relS_for(dist, R)
+    want = oracle.prj_join(R, S, bits)
+    got = ctx.run("prj", R, S, radixBits=bits)
+    assert got["totalMatches"] == want["matches"]
+    assert got["prjChecksum"] == want["checksum"]
+    assert got["radixBits"] == bits
+
+
+def test_prj_reference_checksum_pin(ctx, golden_dir):
+    """PRO "Results" printed by oracle/_ref/mchashjoins (and the closed form behind
+    experiments/new_backup/motivation_log1:8) through the C ABI."""
+    rows = json.load(open(os.path.join(golden_dir, "mc_ref.json")))["rows"]
+    for row in rows:
+        n = row["rSize"]
+        R = hj.generate_data("shuffle", n)
+        S = hj.generate_data("sorted", n)
+        got = ctx.run("prj", R, S, radixBits=14)
+        if row["algo"] == "PRO":
+            assert got["prjChecksum"] == row["results"], (n, got["prjChecksum"])
+        else:
+            assert got["totalMatches"] == row["results"]
+
+
+def test_prj_ragged_skewed_and_r_only(ctx):
+    rng = np.random.default_rng(3)
+    n = 1 << 16
+    R = oracle.generate_data("shuffle", n)
+    S = oracle.generate_zipf(3 * n + 7, n, 0.9, 1)                    # |S| != |R|, skewed, odd
+    assert ctx.run("prj", R, S, radixBits=12)["totalMatches"] == S.size == oracle.true_cardinality(R, S)
+    # all tuples in ONE partition, more than one LDS block of R: the multi-block path
+    R1 = (rng.integers(1, 1 << 14, size=60000, dtype=np.uint64) << np.uint64(8)) | np.uint64(5)
+    S1 = (rng.integers(1, 1 << 14, size=50001, dtype=np.uint64) << np.uint64(8)) | np.uint64(5)
+    want = oracle.prj_join(R1, S1, 8)
+    got = ctx.run("prj", R1, S1, radixBits=8)
+    assert got["totalMatches"] == want["matches"] == oracle.true_cardinality(R1, S1)
+    assert got["prjChecksum"] == want["checksum"]
+    # R-side only (what the fork's PRO actually runs): checksum, no matches
+    got = ctx.run("prj", R, None, radixBits=14)
+    assert got["totalMatches"] == 0 and got["prjChecksum"] == oracle.prj_join(R, None, 14)["checksum"]
+
+
+# ---- full-size, size-independent properties -------------------------------------
+def test_config2_size_properties(ctx):
+    """BASELINE configs[1] size (2^27): invariants that hold for any correct run, plus the
+    reference's logged inputSum for `uniform` (experiments/overflow_log1)."""
+    n = 1 << 27
+    R = hj.generate_data("uniform", n, n, 16)
+    S = hj.generate_data("sorted", n)
+    got = ctx.run("atomic", R, S)
+    assert got["inputSum"] == 9006807263251667
+    assert got["totalMatches"] + got["conflicts"] == n
+    assert got["tableSumFull"] + got["conflictSum"] == got["inputSum"]
+    want = oracle.build_probe_seq(R, S, 4)
+    assert (got["conflicts"], got["totalMatches"]) == (want["conflicts"], want["totalMatches"])
+    del R
+    R = hj.generate_data("local_shuffle", n, n, 1024)
+    for algo, outsum in (("nocc", 9007199187632128), ("atomic", 9007199321849856)):   # probe_log1
+        got = ctx.run(algo, R, S)
+        assert (got["conflicts"], got["totalMatches"], got["inputSum"], got["outputSum"]) == (
+            0, n, 9007199321849856, outsum)
+    got = ctx.run("prj", R, S, radixBits=14)
+    assert got["totalMatches"] == n and got["prjChecksum"] == 549688705024            # motivation_log1:8

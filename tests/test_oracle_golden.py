@@ -1,0 +1,140 @@
+"""The oracle (oracle/hj_oracle.c) against every golden vector the reference holds
+for this path: its committed run logs, the survey's sequential runs of the
+reference headers, and oracle/_ref/mchashjoins outputs. CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+
+def _load(golden_dir, name):
+    with open(os.path.join(golden_dir, name)) as f:
+        return json.load(f)
+
+
+def test_datagen_leading_values(golden_dir):
+    for row in _load(golden_dir, "survey_appendix.json")["appendix_c"]:
+        a = oracle.generate_data(row["dist"], row["n"], row["n"], row["window"])
+        assert a[: len(row["first"])].tolist() == row["first"], row["dist"]
+        assert a[-len(row["last"]):].tolist() == row["last"], row["dist"]
+        assert int(a.sum()) == row["sum"]
+
+
+@pytest.mark.parametrize("max_size", [1 << 20])
+def test_appendix_b_sequential(golden_dir, max_size):
+    for row in _load(golden_dir, "survey_appendix.json")["appendix_b"]:
+        if row["rSize"] > max_size:
+            continue
+        R = oracle.generate_data(row["dist"], row["rSize"], row["rSize"], row["window"])
+        S = oracle.relS_for(row["dist"], R)
+        got = oracle.build_probe_seq(R, S, 4)
+        for k in ("conflicts", "totalMatches", "inputSum", "outputSumNocc"):
+            assert got[k] == row[k], (row, k, got[k])
+        if "outputSumAtomic" in row:
+            assert got["outputSumAtomic"] == row["outputSumAtomic"]
+        # invariant for S = 1..N and keys in [1, N]
+        if row["dist"] != "random":
+            assert got["totalMatches"] + got["conflicts"] == row["rSize"]
+
+
+@pytest.mark.slow
+def test_appendix_b_16m(golden_dir):
+    for row in _load(golden_dir, "survey_appendix.json")["appendix_b"]:
+        if row["rSize"] != 1 << 24 or row["dist"] != "uniform":
+            continue
+        R = oracle.generate_data(row["dist"], row["rSize"], row["rSize"], row["window"])
+        got = oracle.build_probe_seq(R, oracle.relS_for(row["dist"], R), 4)
+        for k in ("conflicts", "totalMatches", "inputSum", "outputSumNocc"):
+            assert got[k] == row[k], (k, got[k], row[k])
+
+
+def test_reference_logs_are_consistent(golden_dir):
+    """Every nocc/atomic line of the reference's logs carries the same counts; keep the
+    distinct expectations so the two heavyweight tests below cover all 300 lines."""
+    logs = _load(golden_dir, "reference_logs.json")
+    seen = {(c["algo"], c["probe"], c["conflicts"], c.get("totalMatches"), c["inputSum"], c["outputSum"])
+            for c in logs["cases"] if c["algo"] in ("nocc", "atomic")}
+    n = 1 << 27
+    tri = n * (n + 1) // 2
+    assert seen == {("nocc", 1, 0, n, tri, tri - n), ("atomic", 1, 0, n, tri, tri),
+                    ("nocc", 0, 0, None, tri, tri - n), ("atomic", 0, 0, None, tri, tri)}
+
+
+@pytest.mark.slow
+def test_reference_log_pins_2p27_local_shuffle(golden_dir):
+    """experiments/new_backup/probe_log*: local_shuffle at 2^27 (W = 1024 run in full)."""
+    logs = _load(golden_dir, "reference_logs.json")
+    want = [c for c in logs["cases"] if c["algo"] == "nocc" and c["probe"] == 1 and c["shuffleRange"] == 1024][0]
+    n = want["rSize"]
+    R = oracle.generate_data("local_shuffle", n, n, 1024)
+    S = oracle.generate_data("sorted", n)
+    got = oracle.build_probe_seq(R, S, 4)
+    assert got["conflicts"] == want["conflicts"] == 0
+    assert got["totalMatches"] == want["totalMatches"]
+    assert got["inputSum"] == want["inputSum"]
+    assert got["outputSumNocc"] == want["outputSum"]
+    atomic = [c for c in logs["cases"] if c["algo"] == "atomic" and c["probe"] == 1][0]
+    assert got["outputSumAtomic"] == atomic["outputSum"]
+
+
+@pytest.mark.slow
+def test_reference_log_pin_2p27_uniform_inputsum(golden_dir):
+    """experiments/overflow_log1: inputSum of `uniform` at 2^27 (DataGen + glibc rand)."""
+    row = _load(golden_dir, "reference_logs.json")["uniform_input_sums"][0]
+    R = oracle.generate_data("uniform", row["rSize"], row["rSize"], row["shuffleRange"])
+    assert int(R.sum(dtype=np.uint64)) == row["inputSum"]
+
+
+def _pro_closed_form(n, bits=14):
+    """sum over k=1..N of (k >> bits) & (nextpow2(N / 2^bits) - 1): the fork's PRO "Results"
+    for unique keys 1..N (every partition holds N/2^bits tuples)."""
+    per = max(n >> bits, 1)
+    mask = (1 << (per - 1).bit_length()) - 1 if per > 1 else 0
+    k = np.arange(1, n + 1, dtype=np.uint64)
+    return int(((k >> np.uint64(bits)) & np.uint64(mask)).sum())
+
+
+def test_prj_checksum_vs_reference_binary(golden_dir):
+    """oracle.prj_join against oracle/_ref/mchashjoins outputs (tests/golden/mc_ref.json)."""
+    for row in _load(golden_dir, "mc_ref.json")["rows"]:
+        n = row["rSize"]
+        if n > 1 << 22:
+            continue
+        R = oracle.generate_data("shuffle", n)
+        S = oracle.generate_data("sorted", n)
+        got = oracle.prj_join(R, S, 14)
+        if row["algo"] == "PRO":
+            assert got["checksum"] == row["results"], (n, got)
+            assert got["checksum"] == _pro_closed_form(n)
+        else:  # NPO: true match count
+            assert got["matches"] == row["results"], (n, got)
+
+
+def test_prj_checksum_vs_reference_log(golden_dir):
+    """experiments/new_backup/motivation_log1:8 -- PRO Results = 549688705024 at 2^27."""
+    mc = {r["algo"]: r for r in _load(golden_dir, "reference_logs.json")["mc"]}
+    assert mc["PRO"]["results"] == [_pro_closed_form(1 << 27)]
+    assert mc["NPO"]["results"] == [1 << 27]
+
+
+def test_prj_matches_equal_true_cardinality():
+    for dist in ("uniform", "random", "shuffle"):
+        n = 1 << 16
+        R = oracle.generate_data(dist, n)
+        S = oracle.relS_for(dist, R)
+        for bits in (4, 9, 14):
+            assert oracle.prj_join(R, S, bits)["matches"] == oracle.true_cardinality(R, S)
+
+
+def test_mt_port_agrees_on_unique_keys():
+    n = 1 << 18
+    R = oracle.generate_data("local_shuffle", n, n, 1024)
+    S = oracle.generate_data("sorted", n)
+    seq = oracle.build_probe_seq(R, S)
+    for atomic in (False, True):
+        mt = oracle.build_probe_mt(R, S, 4, 64, 4, atomic)
+        for k in ("conflicts", "totalMatches", "inputSum", "outputSumNocc", "outputSumAtomic"):
+            assert mt[k] == seq[k]
