@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the other_workloads legs")
     ap.add_argument("--cpu-sample-log2n", type=int, default=27)
+    ap.add_argument("--build-variant", type=int, default=0, help="0 auto, 1 global atomics, 2 LDS window")
     return ap.parse_args()
 
 
@@ -70,14 +71,14 @@ def time_steps(torch, dist_mod, world, fn, steps, warmup):
     return dt
 
 
-def oa_leg(torch, hj, ctx, n, dist, window, steps, warmup, S_dev=None):
+def oa_leg(torch, hj, ctx, n, dist, window, steps, warmup, S_dev=None, variant=0):
     """Open-addressing build+probe on one GPU. Returns (result dict, S_dev)."""
     R = hj.generate_data(dist, n, n, window)
     R_dev = to_device(R, torch, "cuda")
     del R
     if S_dev is None:
         S_dev = torch.arange(1, n + 1, dtype=torch.int64, device="cuda")   # generate_data("sorted"), main.cpp:93
-    ctx.reserve("atomic", n, n)
+    ctx.reserve("atomic", n, n, buildVariant=variant)
     kernel_us = {"clear_us": [], "build_us": [], "probe_us": []}
 
     def step():
@@ -100,6 +101,7 @@ def oa_leg(torch, hj, ctx, n, dist, window, steps, warmup, S_dev=None):
         "mtuples_per_s": 2 * n / (dt / steps) / 1e6,
         "kernel_us": avg,
         "conflicts": res["conflicts"], "totalMatches": res["totalMatches"], "inputSum": res["inputSum"],
+        "buildVariant": res["buildVariant"], "buildDeferred": res["buildDeferred"],
         "checks": {
             "matches_plus_conflicts_eq_rSize": res["totalMatches"] + res["conflicts"] == n,
             "tableSum_plus_conflictSum_eq_inputSum": res["tableSumFull"] + res["conflictSum"] == res["inputSum"],
@@ -179,30 +181,39 @@ def main():
 
     stream = torch.cuda.current_stream().cuda_stream
     ctx = hj.HashJoinContext(local_rank, stream=stream)
-    main_leg, S_dev = oa_leg(torch, hj, ctx, n, a.dist, a.shuffle_range, a.steps, a.warmup)
+    main_leg, S_dev = oa_leg(torch, hj, ctx, n, a.dist, a.shuffle_range, a.steps, a.warmup, variant=a.build_variant)
 
     # roofline of the dominant kernel (the build): algorithmic bytes = 16 B per R tuple
     # (8 read + 8 slot write), duration = HIP-event time of that launch
     ku = main_leg["kernel_us"]
-    dominant = max(("build_us", "probe_us", "clear_us"), key=lambda k: ku[k])
-    alg_bytes = {"build_us": 16.0 * n, "probe_us": 16.0 * n, "clear_us": 16.0 * n}[dominant]
-    achieved = alg_bytes / (ku[dominant] * 1e-6) / 1e9
+    v2 = main_leg["buildVariant"] == 2
+    names = {"build_us": "k_build_own (+k_clear_unowned, k_build_deferred)" if v2 else "k_build_atomic_min",
+             "probe_us": "k_probe", "clear_us": "k_sample_locality" if v2 else "k_fill_empty"}
+    # algorithmic bytes per launch: build = R read 8 + slot write 8 per R tuple;
+    # probe = S read 8 + home-slot read 8 per S tuple; the table clear (16 B per R tuple: 2|R| slots)
+    # is a separate launch in variant 1 and folded into the build in variant 2 (each slot written once)
+    alg = {"build_us": 16.0 * n, "probe_us": 16.0 * n, "clear_us": 0.0 if v2 else 16.0 * n}
+    dominant = max(("build_us", "probe_us"), key=lambda k: ku[k])
+    achieved = alg[dominant] / (ku[dominant] * 1e-6) / 1e9
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
-        traffic = json.load(open(pmc)).get({"build_us": "k_build_atomic_min", "probe_us": "k_probe",
-                                            "clear_us": "k_fill_empty"}[dominant])
-    roofline = {"bound": "hbm", "kernel": {"build_us": "k_build_atomic_min", "probe_us": "k_probe",
-                                           "clear_us": "k_fill_empty"}[dominant],
+        traffic = json.load(open(pmc)).get(names[dominant].split()[0])
+    step_bytes = 48.0 * n      # clear 16 + build 16 + probe 16 per tuple pair, either variant
+    roofline = {"bound": "hbm", "kernel": names[dominant],
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic,
-                "per_kernel_GBps": {k: 16.0 * n / (ku[k] * 1e-6) / 1e9 for k in ku},
-                "whole_step_frac": (48.0 * n) / (main_leg["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+                "algorithmic_bytes_per_launch": alg[dominant],
+                "kernel_us": ku,
+                "per_kernel_GBps": {k: (alg[k] / (ku[k] * 1e-6) / 1e9 if ku[k] > 0 else None) for k in ku},
+                "whole_step_GBps": step_bytes / (main_leg["ms_per_step"] * 1e-3) / 1e9,
+                "whole_step_frac": step_bytes / (main_leg["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
 
     extra = {}
     if not a.no_extra:
         k2 = max(2, a.steps // 2)
-        extra["oa_local_shuffle_1024"], _ = oa_leg(torch, hj, ctx, n, "local_shuffle", 1024, k2, 1, S_dev)
+        extra["oa_local_shuffle_1024"], _ = oa_leg(torch, hj, ctx, n, "local_shuffle", 1024, k2, 1, S_dev,
+                                                   variant=a.build_variant)
         ctx2 = hj.HashJoinContext(local_rank, stream=stream)
         extra["prj_local_shuffle_1024"] = prj_leg(torch, hj, ctx2, n, "local_shuffle", 1024, k2, 1, S_dev)
         ctx2.close()
@@ -223,7 +234,8 @@ def main():
                                f"W={a.shuffle_range}, S=sorted, probeLength=4, tableSize=2|R|; "
                                "step = table clear + build + probe, inputs resident in HBM",
                    "algo": "atomic", "rSize": n, "sSize": n, "dataDistr": a.dist, "shuffleRange": a.shuffle_range},
-        "result": {k: main_leg[k] for k in ("conflicts", "totalMatches", "inputSum", "checks")},
+        "result": {k: main_leg[k] for k in ("conflicts", "totalMatches", "inputSum", "buildVariant",
+                                            "buildDeferred", "checks")},
         "roofline": roofline, "cpu_baseline": cpu, "other_workloads": extra,
     }
     print(json.dumps(line), flush=True)

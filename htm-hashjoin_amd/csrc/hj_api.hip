@@ -15,7 +15,7 @@
 using namespace hj;
 
 namespace {
-enum Ev { EV_CLEAR0, EV_BUILD0, EV_BUILD1, EV_PROBE0, EV_PROBE1, EV_PRJ0, EV_PRJ_PART, EV_PRJ1, EV_COUNT };
+enum Ev { EV_CLEAR0, EV_BUILD0, EV_BUILD_A, EV_BUILD1, EV_PROBE0, EV_PROBE1, EV_PRJ0, EV_PRJ_PART, EV_PRJ1, EV_COUNT };
 }
 
 struct hj_ctx {
@@ -30,6 +30,13 @@ struct hj_ctx {
     uint64_t tableBase = 0;       // first global slot held (0 unless a slice)
     uint64_t rSize = 0, sSize = 0;
     bool built = false;
+    // ownership build (variant 2)
+    void* ownerBuf = nullptr; size_t capOwner = 0;
+    void* queueBuf = nullptr; size_t capQueue = 0;
+    unsigned long long* queueCount = nullptr;   // device
+    unsigned int* fitCount = nullptr;           // device
+    unsigned int* hFit = nullptr;               // pinned
+    uint32_t variantUsed = 1;
     // counters
     Counters* dCtr = nullptr;
     Counters* hCtr = nullptr;     // pinned
@@ -134,7 +141,10 @@ int create_common(int device, void* stream, bool own, hj_ctx** out)
     }
     bool ok = hipMalloc(reinterpret_cast<void**>(&c->dCtr), sizeof(Counters)) == hipSuccess &&
               hipHostMalloc(reinterpret_cast<void**>(&c->hCtr), sizeof(Counters)) == hipSuccess &&
-              hipMalloc(reinterpret_cast<void**>(&c->shardCursors), sizeof(unsigned long long) * 64) == hipSuccess;
+              hipMalloc(reinterpret_cast<void**>(&c->shardCursors), sizeof(unsigned long long) * 64) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&c->queueCount), sizeof(unsigned long long)) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&c->fitCount), sizeof(unsigned int)) == hipSuccess &&
+              hipHostMalloc(reinterpret_cast<void**>(&c->hFit), sizeof(unsigned int)) == hipSuccess;
     for (int i = 0; ok && i < EV_COUNT; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
     if (!ok) { hj_destroy(c); return HJ_ERR_HIP; }
     hipMemset(c->dCtr, 0, sizeof(Counters));
@@ -167,9 +177,11 @@ void hj_destroy(hj_ctx* c)
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream || !c->ownStream) hipStreamSynchronize(c->stream);
-    void* frees[] = {c->table, c->dCtr, c->tmpA, c->partR, c->partS, c->work, c->stageR, c->stageS, c->shardCursors};
+    void* frees[] = {c->table, c->dCtr, c->tmpA, c->partR, c->partS, c->work, c->stageR, c->stageS, c->shardCursors,
+                     c->ownerBuf, c->queueBuf, c->queueCount, c->fitCount};
     for (void* p : frees) if (p) hipFree(p);
     if (c->hCtr) hipHostFree(c->hCtr);
+    if (c->hFit) hipHostFree(c->hFit);
     for (int i = 0; i < EV_COUNT; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
     if (c->ownStream && c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -227,7 +239,21 @@ int hj_reserve(hj_ctx* c, const hj_params* params, uint64_t rSize, uint64_t sSiz
     }
     if (!is_pow2(rSize)) return fail(c, HJ_ERR_INVALID, "hj_reserve: rSize must be a power of two (DataGen.hpp:28, NoCCHashBuild.hpp:36)");
     if (rSize > (1ull << 31)) return fail(c, HJ_ERR_INVALID, "hj_reserve: rSize > 2^31 per device");
-    return grow(c, c->table, c->tableCapSlots, 2 * rSize + kTableSlack);
+    int rc = grow(c, c->table, c->tableCapSlots, 2 * rSize + kTableSlack);
+    if (rc) return rc;
+    if (params->buildVariant > 2) return fail(c, HJ_ERR_INVALID, "hj_reserve: buildVariant must be 0, 1 or 2");
+    if (params->buildVariant != 1 && own_supported(2 * rSize)) {
+        const size_t ob = own_owner_bytes(2 * rSize), qb = own_queue_bytes(rSize);
+        if (ob > c->capOwner) {
+            if (c->ownerBuf) { HJ_HIP(c, hipFree(c->ownerBuf)); c->ownerBuf = nullptr; c->capOwner = 0; }
+            HJ_HIP(c, hipMalloc(&c->ownerBuf, ob)); c->capOwner = ob;
+        }
+        if (qb > c->capQueue) {
+            if (c->queueBuf) { HJ_HIP(c, hipFree(c->queueBuf)); c->queueBuf = nullptr; c->capQueue = 0; }
+            HJ_HIP(c, hipMalloc(&c->queueBuf, qb)); c->capQueue = qb;
+        }
+    }
+    return HJ_OK;
 }
 
 int hj_build_dev(hj_ctx* c, const uint64_t* dR, uint64_t rSize, uint64_t idxBase)
@@ -244,9 +270,33 @@ int hj_build_dev(hj_ctx* c, const uint64_t* dR, uint64_t rSize, uint64_t idxBase
     HJ_HIP(c, hipMemsetAsync(c->dCtr, 0, sizeof(Counters), c->stream));
     int rc;
     if ((rc = record(c, EV_CLEAR0))) return rc;
-    launch_fill_empty(c->table, c->tableSize + kTableSlack, c->stream);
-    if ((rc = record(c, EV_BUILD0))) return rc;
-    launch_build_atomic_min(dR, rSize, c->table, c->tableSize, probe_len(c->params), idxBase, c->dCtr, c->stream);
+    // which build kernel: 2 needs its buffers (hj_reserve) and a table of at least one window
+    uint32_t variant = c->params.buildVariant;
+    const bool canOwn = own_supported(c->tableSize) && c->capOwner >= own_owner_bytes(c->tableSize) &&
+                        c->capQueue >= own_queue_bytes(rSize);
+    if (variant == 2 && !canOwn) variant = 1;
+    if (variant == 0) {
+        variant = 1;
+        if (canOwn) {
+            // locality pre-round: 256 sample tiles; take the LDS-window kernel if >= 7/8 of them fit
+            const uint32_t nSample = 256;
+            launch_sample_locality(dR, rSize, c->tableSize, nSample, c->fitCount, c->stream);
+            HJ_HIP(c, hipMemcpyAsync(c->hFit, c->fitCount, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+            HJ_HIP(c, hipStreamSynchronize(c->stream));
+            if (*c->hFit * 8 >= nSample * 7) variant = 2;
+        }
+    }
+    c->variantUsed = variant;
+    if (variant == 2) {
+        if ((rc = record(c, EV_BUILD0))) return rc;
+        launch_build_own(dR, rSize, c->table, c->tableSize, probe_len(c->params), idxBase, c->ownerBuf, c->queueBuf,
+                         c->queueCount, c->dCtr, c->ev[EV_BUILD_A], c->stream);
+        c->evSet[EV_BUILD_A] = true;
+    } else {
+        launch_fill_empty(c->table, c->tableSize + kTableSlack, c->stream);
+        if ((rc = record(c, EV_BUILD0))) return rc;
+        launch_build_atomic_min(dR, rSize, c->table, c->tableSize, probe_len(c->params), idxBase, c->dCtr, c->stream);
+    }
     if ((rc = record(c, EV_BUILD1))) return rc;
     HJ_HIP(c, hipGetLastError());
     c->built = true;
@@ -355,7 +405,8 @@ int hj_fetch_result(hj_ctx* c, hj_result* out)
         out->tableSumHalf = k.tableSumHalf;
         out->tableSumFull = k.tableSumFull;
         out->outputSum = (c->params.algo == HJ_ALGO_NOCC ? k.tableSumHalf : k.tableSumFull) + k.conflictSum;
-        out->buildVariant = 1;
+        out->buildVariant = c->variantUsed;
+        out->buildDeferred = k.spare[0];
         out->clear_us = elapsed_us(c, EV_CLEAR0, EV_BUILD0);
         out->build_us = elapsed_us(c, EV_BUILD0, EV_BUILD1);
         out->probe_us = elapsed_us(c, EV_PROBE0, EV_PROBE1);

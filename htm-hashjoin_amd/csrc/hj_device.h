@@ -52,6 +52,18 @@ void launch_shard_scatter(const uint64_t* in, uint64_t n, uint32_t nShards, uint
                           unsigned long long* cursors, uint64_t packIdxBase,
                           uint64_t* out, hipStream_t s);
 
+// ---- ownership build (defined in hj_build_own.hip) ---------------------------
+size_t own_queue_bytes(uint64_t rSize);
+size_t own_owner_bytes(uint64_t tableSize);
+bool   own_supported(uint64_t tableSize);
+void launch_sample_locality(const uint64_t* R, uint64_t n, uint64_t tableSize, uint32_t nSample,
+                            unsigned int* fitCount, hipStream_t s);
+// phase A (LDS window) -> clear of unowned blocks -> phase B (deferred tuples).
+// Writes every table slot exactly once: no separate launch_fill_empty needed.
+void launch_build_own(const uint64_t* R, uint64_t n, uint64_t* table, uint64_t tableSize, uint32_t probeLen,
+                      uint64_t idxBase, void* ownerBuf, void* queueBuf, unsigned long long* queueCount,
+                      Counters* ctr, hipEvent_t evPhaseA, hipStream_t s);
+
 // ---- PRJ (defined in hj_prj.hip) -------------------------------------------
 struct PrjPlan {
     uint32_t radixBits;   // total

@@ -45,11 +45,12 @@ def generate_data(dist, size_in_tuples, distinct_keys=None, local_shuffle_range=
     return out
 
 
-def _params(algo, scaleOutput=2, numPartitions=64, probeLength=4, transactionSize=16, radixBits=0):
+def _params(algo, scaleOutput=2, numPartitions=64, probeLength=4, transactionSize=16, radixBits=0,
+            buildVariant=0):
     p = hj_params()
     p.algo = _lib.ALGO_IDS[algo]
     p.scaleOutput, p.numPartitions, p.probeLength = scaleOutput, numPartitions, probeLength
-    p.transactionSize, p.radixBits = transactionSize, radixBits
+    p.transactionSize, p.radixBits, p.buildVariant = transactionSize, radixBits, buildVariant
     return p
 
 

@@ -66,8 +66,9 @@ typedef struct {
     uint32_t transactionSize; /* default 16 (main.cpp:82); echoed for htm       */
     uint32_t radixBits;       /* PRJ only. 0 = auto (>= 14 so that every
                                  R partition fits one LDS table)                */
-    uint32_t buildVariant;    /* 0 = auto; 1 = global atomicMin kernel;
-                                 2 = LDS-window ownership kernel                */
+    uint32_t buildVariant;    /* 0 = auto (samples R for locality, like the pre-round of
+                                 HTMHashBuild.hpp:100-154); 1 = global atomicMin kernel;
+                                 2 = block-ownership + LDS-window kernel          */
     uint32_t reserved[5];
 } hj_params;
 
@@ -94,7 +95,9 @@ typedef struct {
     double clear_us, build_us, probe_us, partition_us, join_us, total_us;
     double h2d_us;            /* hj_run only: host->device copies (reported
                                  separately, never part of total_us)              */
-    uint64_t reserved[4];
+    uint64_t buildDeferred;   /* buildVariant 2: tuples that left the LDS window and
+                                 were finished by the global-atomic phase            */
+    uint64_t reserved[3];
 } hj_result;
 
 typedef struct hj_ctx hj_ctx;

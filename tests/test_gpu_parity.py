@@ -30,14 +30,20 @@ DISTS = [("uniform", 16), ("uniform", 2), ("random", 16), ("sorted", 16), ("shuf
          ("local_shuffle", 16), ("local_shuffle", 1024)]
 
 
-@pytest.mark.parametrize("dist,window", DISTS)
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("dist,window", DISTS + [("local_shuffle", 4096), ("local_shuffle", 65536)])
 @pytest.mark.parametrize("n", [1 << 10, 1 << 16, 1 << 20])
-def test_build_probe_matches_sequential_oracle(ctx, dist, window, n):
+def test_build_probe_matches_sequential_oracle(ctx, dist, window, n, variant):
+    """variant 1 = global atomicMin kernel, 2 = block ownership + LDS window (+ deferred phase):
+    both must give the table a single thread builds in input order, slot for slot."""
     R = oracle.generate_data(dist, n, n, window)
     S = oracle.relS_for(dist, R)
     want = oracle.build_probe_seq(R, S, 4, want_table=True)
-    got = ctx.run("atomic", R, S)
+    got = ctx.run("atomic", R, S, buildVariant=variant)
     check_oa(got, want)
+    assert got["buildVariant"] == (variant if n >= 4096 else 1)
+    if variant == 2 and n >= 4096 and dist in ("sorted", "uniform") :
+        assert got["buildDeferred"] < n // 8          # locality: the LDS window takes almost everything
     # the whole table, slot for slot, equals the table a single thread builds in input order
     assert np.array_equal(ctx.export_table(2 * n), want["table"])
 
@@ -61,9 +67,43 @@ def test_other_probe_lengths(ctx, probe_length):
     R = oracle.generate_data("uniform", n, n, 16)
     S = oracle.generate_data("sorted", n)
     want = oracle.build_probe_seq(R, S, probe_length, want_table=True)
-    got = ctx.run("atomic", R, S, probeLength=probe_length)
-    check_oa(got, want)
-    assert np.array_equal(ctx.export_table(2 * n), want["table"])
+    for variant in (1, 2):
+        got = ctx.run("atomic", R, S, probeLength=probe_length, buildVariant=variant)
+        check_oa(got, want)
+        assert np.array_equal(ctx.export_table(2 * n), want["table"])
+
+
+def test_auto_variant_follows_locality(ctx):
+    """buildVariant 0 samples R (the pre-round of HTMHashBuild.hpp:100-154): near-sorted input takes
+    the LDS-window kernel, a random permutation the global-atomic one; results equal either way."""
+    n = 1 << 20
+    S = oracle.generate_data("sorted", n)
+    for dist, window, expect in (("uniform", 16, 2), ("local_shuffle", 1024, 2), ("shuffle", 16, 1), ("random", 16, 1)):
+        R = oracle.generate_data(dist, n, n, window)
+        Sx = oracle.relS_for(dist, R)
+        got = ctx.run("atomic", R, Sx)
+        assert got["buildVariant"] == expect, (dist, got["buildVariant"])
+        check_oa(got, oracle.build_probe_seq(R, Sx, 4))
+
+
+def test_unaligned_device_pointers(ctx):
+    """R and S handed over at an odd tuple offset (8-byte, not 16-byte aligned)."""
+    import torch
+    n = 1 << 16
+    R = oracle.generate_data("uniform", n, n, 16)
+    S = oracle.generate_data("sorted", n)
+    want = oracle.build_probe_seq(R, S, 4, want_table=True)
+    dR = torch.zeros(n + 1, dtype=torch.int64, device="cuda"); dR[1:] = torch.from_numpy(R.view("int64")).cuda()
+    dS = torch.zeros(n + 1, dtype=torch.int64, device="cuda"); dS[1:] = torch.from_numpy(S.view("int64")).cuda()
+    for variant in (1, 2):
+        with hj.HashJoinContext(0) as c2:
+            c2.reserve("atomic", n, n, buildVariant=variant)
+            c2.build(dR.data_ptr() + 8, n)
+            c2.probe(dS.data_ptr() + 8, n)
+            c2.checksums()
+            got = c2.fetch()
+            check_oa(got, want)
+            assert np.array_equal(c2.export_table(2 * n), want["table"])
 
 
 def test_heavy_duplicates_and_tiny_sizes(ctx):
@@ -72,21 +112,23 @@ def test_heavy_duplicates_and_tiny_sizes(ctx):
         R = rng.integers(1, hi, size=n, dtype=np.uint64)
         S = rng.integers(1, hi + 3, size=3 * n + 1, dtype=np.uint64)   # |S| != |R|, odd length
         want = oracle.build_probe_seq(R, S, 4, want_table=True)
-        got = ctx.run("atomic", R, S)
-        check_oa(got, want)
-        assert np.array_equal(ctx.export_table(2 * n), want["table"])
+        for variant in (1, 2):
+            got = ctx.run("atomic", R, S, buildVariant=variant)
+            check_oa(got, want)
+            assert np.array_equal(ctx.export_table(2 * n), want["table"])
 
 
 def test_wraparound_at_table_end(ctx):
-    n = 1 << 10
+    n = 1 << 13
     # keys whose home slots are the last slots of the 2n-slot table: probing must wrap (:52)
     R = np.full(n, 2 * n - 1, dtype=np.uint64)
     R[::3] = 2 * n - 2
     S = np.array([2 * n - 1, 2 * n - 2, 1, 2, 4 * n - 1], dtype=np.uint64)
     want = oracle.build_probe_seq(R, S, 4, want_table=True)
-    got = ctx.run("atomic", R, S)
-    check_oa(got, want)
-    assert np.array_equal(ctx.export_table(2 * n), want["table"])
+    for variant in (1, 2):
+        got = ctx.run("atomic", R, S, buildVariant=variant)
+        check_oa(got, want)
+        assert np.array_equal(ctx.export_table(2 * n), want["table"])
 
 
 def test_build_only_and_empty_probe(ctx):
