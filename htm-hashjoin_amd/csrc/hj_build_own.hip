@@ -38,17 +38,19 @@
 
 #include "hj_device.h"
 
+#include <cstdlib>
+
 namespace hj {
 
 constexpr int kOwnThreads = 512;                 // 8 wavefronts
-constexpr int kOwnVecPerThread = 2;              // 16-byte loads per thread per tile
-constexpr int kOwnTile = kOwnThreads * kOwnVecPerThread * 2;   // 2048 tuples
+constexpr int kPerThread = 8;                    // tuples per thread per tile (8-byte loads)
+constexpr int kOwnTile = kOwnThreads * kPerThread;   // 4096 tuples
+constexpr int kWaveSpan = 64 * kPerThread;       // consecutive tuples one wavefront takes per tile
 constexpr uint32_t kBlkShift = 9;
 constexpr uint32_t kBlkSlots = 1u << kBlkShift;  // 512 slots = 4 KiB
 constexpr uint32_t kWinBlocks = 16;
 constexpr uint32_t kWinSlots = kBlkSlots * kWinBlocks;   // 8192 slots = 64 KiB
-constexpr uint32_t kBackBlocks = 4;              // window keeps this much room behind a tile's lowest key
-constexpr int kPerThread = kOwnVecPerThread * 2;
+constexpr uint32_t kBackBlocks = 2;              // window keeps this much room behind a tile's lowest key
 
 struct DeferredEntry { uint64_t pos; uint64_t packed; };
 
@@ -62,85 +64,172 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
     return v;
 }
 
+__device__ __forceinline__ uint64_t pack64(uint32_t hi, uint32_t lo) { return ((uint64_t)hi << 32) | lo; }
+
+constexpr int kQCap = 128;                        // per-wavefront retry queue entries (LDS)
+
 // owner[blk]: 0 = free, otherwise (workgroup id + 1).
-__global__ void __launch_bounds__(kOwnThreads)
+// PACKED = false: R holds DataGen tuples (value = key), index = idxBase + position.
+// PACKED = true : R holds (globalIdx << keyBits | key') from hj_shard_scatter_dev.
+//
+// rocprof showed the first versions VALU-issue bound (120 VALU + 90 SALU instructions per 64
+// tuples on unique keys, 5x that on duplicate-heavy `uniform`, LDS <10 % busy), so the insert is
+// split in two:
+//   fast step   64 consecutive tuples (lanes in input order) each try their home slot once with an
+//               LDS atomicMin. Unique, in-window, owned -> done in ~10 instructions.
+//   retry queue whatever did not finish (slot taken, displaced a later tuple, block not owned) is
+//               pushed -- compacted with a ballot -- to a small per-wavefront LDS queue as
+//               (slot, value). Full rounds (ownership test, look-before-leap over the probe window,
+//               atomicMin) run on 64 queue entries at a time, so every round is dense regardless of
+//               how long individual probe/displacement chains get.
+// All per-tuple arithmetic is 32-bit: key = low word, slot numbers < 2^32, value = {key, index}.
+template <bool PACKED, int ABL = 0>
+__global__ void __launch_bounds__(kOwnThreads, 4)
 k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
-            uint64_t* __restrict__ table, uint64_t mask, uint32_t probeLen, uint64_t idxBase,
+            uint64_t* __restrict__ table, uint64_t mask, uint64_t keyMask, uint32_t probeLen, uint64_t idxBase,
             unsigned int* __restrict__ owner, DeferredEntry* __restrict__ queue,
             unsigned long long* __restrict__ queueCount, Counters* __restrict__ ctr)
 {
     extern __shared__ uint64_t win[];            // kWinSlots slots, ring indexed by (slot & (kWinSlots-1))
-    __shared__ unsigned int owned[kWinBlocks];   // per ring block: 1 = claimed by this workgroup
+    __shared__ unsigned int owned[kWinBlocks];   // per ring block: 0 = not tried yet, 1 = claimed by this workgroup, 2 = someone else's
+    __shared__ unsigned int need[kWinBlocks];    // per ring block: wanted by the current tile (count, or 0x10000 = unconditional)
     __shared__ unsigned int sTileMin;
-    __shared__ unsigned int sDefCount;
-    __shared__ unsigned long long sDefBase;
+    __shared__ uint32_t qPos[kOwnThreads / 64][kQCap], qLo[kOwnThreads / 64][kQCap], qHi[kOwnThreads / 64][kQCap];
 
     const uint64_t cb = (uint64_t)blockIdx.x * chunkLen;
     if (cb >= n) return;
     const uint64_t ce = (cb + chunkLen < n) ? cb + chunkLen : n;
-    const uint32_t numBlocks = (uint32_t)((mask + 1) >> kBlkShift);   // table blocks (tableSize >= kBlkSlots, host-checked)
-    const uint32_t blkMask = numBlocks - 1;
+    const uint32_t clen = (uint32_t)(ce - cb);                        // chunk length (< 2^32)
+    const uint32_t mask32 = (uint32_t)mask;                           // tableSize <= 2^32 slots
+    const uint32_t kmask32 = (uint32_t)keyMask;
+    const uint32_t numBlocks = (uint32_t)((mask + 1) >> kBlkShift);   // tableSize >= kWinSlots, host-checked
     const uint32_t me = blockIdx.x + 1;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t* __restrict__ Rc = R + cb;                          // this chunk
+    const uint32_t idx0 = (uint32_t)(idxBase + cb);                    // index of the chunk's first tuple (fits 32 bits, host-checked)
+    uint32_t* const myQPos = qPos[wave]; uint32_t* const myQLo = qLo[wave]; uint32_t* const myQHi = qHi[wave];
 
     for (uint32_t i = threadIdx.x; i < kWinSlots; i += kOwnThreads) win[i] = kEmpty;
-    if (threadIdx.x < kWinBlocks) owned[threadIdx.x] = 0;
-    if (threadIdx.x == 0) { sTileMin = 0xFFFFFFFFu; sDefCount = 0; }
+    if (threadIdx.x < kWinBlocks) { owned[threadIdx.x] = 0; need[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) sTileMin = 0xFFFFFFFFu;
     __syncthreads();
 
-    // window = table blocks [wb, wb + kWinBlocks); haveWin = false until the first tile
-    uint32_t wb = 0;
-    bool haveWin = false;
-    unsigned long long drops = 0, dropSum = 0, inSum = 0, bad = 0, deferred = 0;
+    uint32_t wb = 0;                 // window = table blocks [wb, wb + kWinBlocks)
+    bool haveWin = false;            // false until the first tile with a valid tuple
+    unsigned long long dropSum = 0, inSum = 0;
+    uint32_t drops = 0, bad = 0, deferred = 0;
+    uint32_t ownedMask = 0;          // bit r: ring block r is mine (refreshed per tile)
+    uint32_t qCount = 0;             // entries in this wavefront's retry queue (wave-uniform)
 
-    // element e sits at R + e; a 16-byte load needs (R + e) 16-byte aligned, i.e. (e + a0) even
-    const long long a0 = (reinterpret_cast<uintptr_t>(R) & 8) ? 1 : 0;
-    const long long lcb = (long long)cb, lce = (long long)ce;
-    const long long tb0 = lcb - ((lcb + a0) & 1);   // may be cb-1 (even -1): lanes mask elements outside [cb, ce)
-
-    // loads one tile into registers; raw[] holds 2 tuples per 16-byte vector
-    auto load_tile = [&](long long tb, uint64_t (&raw)[kPerThread]) {
-#pragma unroll
-        for (int k = 0; k < kOwnVecPerThread; ++k) {
-            const long long e = tb + 2 * ((long long)k * kOwnThreads + threadIdx.x);
-            const bool inx = e >= lcb && e < lce, iny = e + 1 >= lcb && e + 1 < lce;
-            uint64_t x = 0, y = 0;
-            if (inx && iny) {
-                const ulonglong2 t = *reinterpret_cast<const ulonglong2*>(R + e);
-                x = t.x; y = t.y;
+    // One dense retry round over up to 64 queue entries (popped from the tail). Unfinished entries
+    // are pushed back. Terminal events: placed, dropped (budget exhausted), deferred (block not owned).
+    auto retry_round = [&]() {
+        const uint32_t take = qCount < 64u ? qCount : 64u;
+        qCount -= take;
+        const bool has = lane < take;
+        uint32_t pos = 0, mlo = 0, mhi = 0;
+        if (has) { pos = myQPos[qCount + lane]; mlo = myQLo[qCount + lane]; mhi = myQHi[qCount + lane]; }
+        bool again = false, toDefer = false;
+        if (has) {
+            const uint32_t key = PACKED ? (mlo & kmask32) : mlo;
+            uint32_t budget = probeLen - ((pos - (key & mask32)) & mask32);
+            const uint32_t blk = pos >> kBlkShift;
+            if (budget == 0) {                                          // NoCCHashBuild.hpp:57-58
+                drops += 1; dropSum += key;
+            } else if (blk - wb >= kWinBlocks || !((ownedMask >> (blk & (kWinBlocks - 1))) & 1u)) {
+                toDefer = true;                                         // abort -> global deferred queue
             } else {
-                if (inx) x = R[e];
-                if (iny) y = R[e + 1];
+                const uint64_t mine = pack64(mhi, mlo);
+                uint32_t skip = 0;
+                if ((pos & (kBlkSlots - 1)) <= kBlkSlots - 4) {
+                    // the next 4 slots sit in this (owned) block: look before leaping. Slot values
+                    // only decrease, so a slot seen below `mine` stays below it.
+                    const uint64_t* w = &win[pos & (kWinSlots - 1)];
+                    const uint64_t v0 = w[0], v1 = w[1], v2 = w[2], v3 = w[3];
+                    if (v0 < mine) { skip = 1; if (v1 < mine) { skip = 2; if (v2 < mine) { skip = 3; if (v3 < mine) skip = 4; } } }
+                    skip = skip < budget ? skip : budget;
+                    pos = (pos + skip) & mask32; budget -= skip;
+                }
+                if (budget == 0) {
+                    drops += 1; dropSum += key;
+                } else if (skip == 4) {
+                    again = true;                                       // may have left the block: re-check next round
+                } else {
+                    const unsigned long long old =
+                        atomicMin(reinterpret_cast<unsigned long long*>(&win[pos & (kWinSlots - 1)]), (unsigned long long)mine);
+                    if (old != kEmpty && old != mine) {
+                        if (old > mine) { mlo = (uint32_t)old; mhi = (uint32_t)(old >> 32); }   // displaced: carry it on
+                        pos = (pos + 1) & mask32;
+                        again = true;
+                    }
+                }
             }
-            raw[2 * k] = x; raw[2 * k + 1] = y;
         }
+        // deferred tuples leave for the global queue (one returning atomic per round that has any)
+        const unsigned long long dm = __ballot(toDefer);
+        if (dm) {
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(queueCount, (unsigned long long)__popcll(dm));
+            base = __shfl(base, 0, 64);
+            if (toDefer) {
+                const unsigned long long at = base + __popcll(dm & ((1ull << lane) - 1ull));
+                queue[at].pos = pos; queue[at].packed = pack64(mhi, mlo);
+                deferred += 1;
+            }
+        }
+        const unsigned long long am = __ballot(again);
+        if (again) {
+            const uint32_t at = qCount + (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
+            myQPos[at] = pos; myQLo[at] = mlo; myQHi[at] = mhi;
+        }
+        qCount += (uint32_t)__popcll(am);
     };
 
+    // tile t covers chunk offsets [t*kOwnTile, ...); this thread's tuple j sits at offset
+    // t*kOwnTile + wave*kWaveSpan + 64 j + lane
+    const uint32_t tOff = wave * kWaveSpan + lane;
     uint64_t nxt[kPerThread];
-    load_tile(tb0, nxt);
-    for (long long tb = tb0; tb < lce; tb += kOwnTile) {
+#pragma unroll
+    for (int j = 0; j < kPerThread; ++j) {
+        const uint32_t o = tOff + 64 * j;
+        nxt[j] = o < clen ? Rc[o] : 0;
+    }
+
+    for (uint32_t tb = 0; tb < clen; tb += kOwnTile) {
         // ---- take the prefetched tile, start loading the next one ----
-        uint64_t key[kPerThread];
-        uint64_t gidx[kPerThread];
-        bool live[kPerThread];
+        uint32_t klo[kPerThread], khi[kPerThread];
+#pragma unroll
+        for (int j = 0; j < kPerThread; ++j) { klo[j] = (uint32_t)nxt[j]; khi[j] = (uint32_t)(nxt[j] >> 32); }
+        const bool full = tb + kOwnTile <= clen;                      // wave-uniform
+        const bool firstTile = tb == 0, lastTile = tb + kOwnTile >= clen;
+        if (!lastTile) {
+#pragma unroll
+            for (int j = 0; j < kPerThread; ++j) {
+                const uint32_t o = tb + kOwnTile + tOff + 64 * j;
+                nxt[j] = o < clen ? Rc[o] : 0;
+            }
+        }
+        uint32_t liveMask = 0;
         uint32_t myMin = 0xFFFFFFFFu;
 #pragma unroll
-        for (int k = 0; k < kOwnVecPerThread; ++k) {
-            const long long e = tb + 2 * ((long long)k * kOwnThreads + threadIdx.x);
-            key[2 * k] = nxt[2 * k]; key[2 * k + 1] = nxt[2 * k + 1];
-            gidx[2 * k] = idxBase + (uint64_t)e; gidx[2 * k + 1] = idxBase + (uint64_t)(e + 1);
-            live[2 * k] = e >= lcb && e < lce; live[2 * k + 1] = e + 1 >= lcb && e + 1 < lce;
-        }
-        if (tb + kOwnTile < lce) load_tile(tb + kOwnTile, nxt);
-#pragma unroll
         for (int j = 0; j < kPerThread; ++j) {
-            if (!live[j]) continue;
-            inSum += key[j];
-            if ((key[j] >> 32) != 0 || key[j] == 0) { bad += 1; live[j] = false; continue; }
-            const uint32_t hb = (uint32_t)((key[j] & mask) >> kBlkShift);
-            myMin = hb < myMin ? hb : myMin;
+            const bool in = full || (tb + tOff + 64 * j < clen);
+            bool ok = in;
+            if (PACKED) {
+                klo[j] = klo[j];                                         // key' = klo & kmask32 (keyBits <= 32)
+                if (in) inSum += klo[j] & kmask32;
+            } else {
+                if (in) inSum += pack64(khi[j], klo[j]);
+                if (in && (khi[j] != 0 || klo[j] == 0)) { bad += 1; ok = false; }
+            }
+            if (ok) {
+                liveMask |= 1u << j;
+                const uint32_t hb = ((PACKED ? (klo[j] & kmask32) : klo[j]) & mask32) >> kBlkShift;
+                myMin = hb < myMin ? hb : myMin;
+            }
         }
         myMin = wave_min_u32(myMin);
-        if ((threadIdx.x & 63) == 0 && myMin != 0xFFFFFFFFu) atomicMin(&sTileMin, myMin);
+        if (lane == 0 && myMin != 0xFFFFFFFFu) atomicMin(&sTileMin, myMin);
         __syncthreads();
         const uint32_t tmin = sTileMin;          // 0xFFFFFFFF if the tile holds no valid tuple
         __syncthreads();
@@ -149,90 +238,119 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
         // ---- slide the window ----
         if (tmin != 0xFFFFFFFFu) {
             uint32_t nb = tmin > kBackBlocks ? tmin - kBackBlocks : 0;
-            if (nb + kWinBlocks > numBlocks) nb = numBlocks > kWinBlocks ? numBlocks - kWinBlocks : 0;
+            if (nb + kWinBlocks > numBlocks) nb = numBlocks - kWinBlocks;
             if (!haveWin) {
-                // first window: claim all its blocks
-                wb = nb;
-                if (threadIdx.x < kWinBlocks && wb + threadIdx.x < numBlocks) {
-                    const uint32_t blk = wb + threadIdx.x;
-                    owned[blk & (kWinBlocks - 1)] = (atomicCAS(&owner[blk], 0u, me) == 0u) ? 1u : 0u;
-                }
+                wb = nb;             // first window; blocks are claimed lazily below
                 haveWin = true;
-                __syncthreads();
             } else if (nb > wb) {
                 // retire blocks [wb, min(nb, wb+K)): owned ones go to HBM whole, then reset
                 const uint32_t nRetire = (nb - wb) < kWinBlocks ? (nb - wb) : kWinBlocks;
                 for (uint32_t r = 0; r < nRetire; ++r) {
                     const uint32_t blk = wb + r, ring = blk & (kWinBlocks - 1);
-                    if (owned[ring]) {
+                    if (owned[ring] == 1) {
                         ulonglong2* dst = reinterpret_cast<ulonglong2*>(table + ((uint64_t)blk << kBlkShift));
                         ulonglong2* src = reinterpret_cast<ulonglong2*>(win + ((uint64_t)ring << kBlkShift));
                         for (uint32_t v = threadIdx.x; v < kBlkSlots / 2; v += kOwnThreads) {
-                            dst[v] = src[v];
+                            if (!(ABL & 4)) dst[v] = src[v];
                             src[v] = make_ulonglong2(kEmpty, kEmpty);
                         }
                     }
                 }
                 __syncthreads();
-                // claim the blocks that enter: [max(wb+K, nb), nb+K)
-                const uint32_t enter0 = (wb + kWinBlocks > nb) ? wb + kWinBlocks : nb;
-                if (threadIdx.x < kWinBlocks) {
-                    const uint32_t blk = enter0 + threadIdx.x;
-                    if (blk < nb + kWinBlocks && blk < numBlocks)
-                        owned[blk & (kWinBlocks - 1)] = (atomicCAS(&owner[blk], 0u, me) == 0u) ? 1u : 0u;
-                }
+                // the ring positions just vacated now stand for the blocks that enter: not tried yet
+                if (threadIdx.x < nRetire) owned[(wb + threadIdx.x) & (kWinBlocks - 1)] = 0;
                 wb = nb;
-                __syncthreads();
             }
         }
 
-        // ---- insert (index priority on LDS) ----
-        uint64_t dpos[kPerThread], dval[kPerThread];
-        int nd = 0;
+        // ---- claim, lazily, the blocks this tile needs ----
+        // need[ring]: wanted blocks (home block; also the next block when a probe window straddles
+        // the block end). In a chunk's first and last tile the home blocks are COUNTED and a block is
+        // claimed only if it holds at least 1/4 of what the tile's fullest block holds: stragglers
+        // across a chunk seam must not take a whole block from the neighbour chunk that fills it
+        // (they are deferred instead). Elsewhere any touched block is claimed.
+        const bool seamTile = firstTile || lastTile;
+        if (haveWin) {
+#pragma unroll
+            for (int j = 0; j < kPerThread; ++j) {
+                const uint32_t home = (PACKED ? (klo[j] & kmask32) : klo[j]) & mask32;
+                const uint32_t hb = home >> kBlkShift;
+                const bool lv = (liveMask >> j) & 1u;
+                uint32_t r0 = (lv && hb - wb < kWinBlocks) ? (hb & (kWinBlocks - 1)) : 0xFFu;
+                if (lv && (home & (kBlkSlots - 1)) > kBlkSlots - probeLen) {
+                    const uint32_t eb = ((home + probeLen - 1) & mask32) >> kBlkShift;
+                    if (eb - wb < kWinBlocks) need[eb & (kWinBlocks - 1)] = 0x10000u;   // straddle: always wanted
+                }
+                if (seamTile) {
+                    // wave-aggregated counting: near-sorted input puts a wavefront in 1-2 blocks
+                    for (;;) {
+                        const unsigned long long act = __ballot(r0 != 0xFFu);
+                        if (!act) break;
+                        const uint32_t lead = __shfl(r0, __ffsll((long long)act) - 1, 64);
+                        const unsigned long long same = __ballot(r0 == lead);
+                        if (lane == (uint32_t)(__ffsll((long long)same) - 1)) atomicAdd(&need[lead], (unsigned int)__popcll(same));
+                        if (r0 == lead) r0 = 0xFFu;
+                    }
+                } else {
+                    // common case: the whole wavefront step sits in one block -> one LDS store
+                    const uint32_t lead = __builtin_amdgcn_readfirstlane(r0);
+                    if (__ballot(r0 != lead) == 0ull) { if (lane == 0 && lead != 0xFFu) need[lead] = 0x10000u; }
+                    else if (r0 != 0xFFu) need[r0] = 0x10000u;
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const uint32_t t = threadIdx.x;
+            const uint32_t c = t < kWinBlocks ? need[t] : 0;
+            uint32_t mx = c < 0x10000u ? c : 0;      // fullest COUNTED block (flags are not counts)
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(mx, off, 64); mx = o > mx ? o : mx; }
+            if (t < kWinBlocks) {
+                need[t] = 0;
+                if (c && (c >= 0x10000u || c * 4 >= mx) && owned[t] == 0) {
+                    const uint32_t blk = wb + ((t - wb) & (kWinBlocks - 1));   // ring position -> block in [wb, wb+K)
+                    if (ABL & 2) owned[t] = 1u;
+                    else owned[t] = (blk < numBlocks && atomicCAS(&owner[blk], 0u, me) == 0u) ? 1u : 2u;
+                }
+            }
+        }
+        __syncthreads();
+        // one LDS read per wavefront: bit r = ring block r is mine
+        ownedMask = (uint32_t)__ballot(lane < kWinBlocks && owned[lane & (kWinBlocks - 1)] == 1u && haveWin);
+
+        // ---- insert: fast step per 64 consecutive tuples, everything else through the retry queue ----
 #pragma unroll
         for (int j = 0; j < kPerThread; ++j) {
-            if (!live[j]) continue;
-            uint64_t mine = (gidx[j] << 32) | key[j];
-            uint64_t pos = key[j] & mask;
-            uint32_t budget = probeLen;
-            for (;;) {
-                if (budget == 0) { drops += 1; dropSum += (uint32_t)mine; break; }   // NoCCHashBuild.hpp:57-58
-                const uint32_t blk = (uint32_t)(pos >> kBlkShift);
-                const bool mineBlk = haveWin && blk >= wb && blk < wb + kWinBlocks && owned[blk & (kWinBlocks - 1)];
-                if (!mineBlk) { dpos[nd] = pos; dval[nd] = mine; ++nd; break; }      // abort -> deferred queue
+            if (ABL & 1) break;
+            while (qCount >= 64u) retry_round();                        // keep room for one full step
+            const bool lv = (liveMask >> j) & 1u;
+            uint32_t mlo = klo[j];
+            uint32_t mhi = PACKED ? khi[j] : (idx0 + tb + tOff + 64 * j);
+            uint32_t pos = (PACKED ? (klo[j] & kmask32) : klo[j]) & mask32;
+            const uint32_t blk = pos >> kBlkShift;
+            const bool own = lv && (blk - wb < kWinBlocks) && ((ownedMask >> (blk & (kWinBlocks - 1))) & 1u);
+            bool again = lv && !own;                                    // not owned: the retry round defers it
+            if (own) {
+                const uint64_t mine = pack64(mhi, mlo);
                 const unsigned long long old =
                     atomicMin(reinterpret_cast<unsigned long long*>(&win[pos & (kWinSlots - 1)]), (unsigned long long)mine);
-                if (old == kEmpty || old == mine) break;
-                if (old > mine) {
-                    mine = old;
-                    const uint64_t home = (uint32_t)old & mask;
-                    budget = probeLen - ((uint32_t)((pos - home) & mask) + 1);
-                } else {
-                    budget -= 1;
+                if (old != kEmpty) {
+                    if (old > mine) { mlo = (uint32_t)old; mhi = (uint32_t)(old >> 32); }   // displaced a later tuple
+                    pos = (pos + 1) & mask32;
+                    again = true;
                 }
-                pos = (pos + 1) & mask;
+            }
+            const unsigned long long am = __ballot(again);
+            if (am) {
+                if (again) {
+                    const uint32_t at = qCount + (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
+                    myQPos[at] = pos; myQLo[at] = mlo; myQHi[at] = mhi;
+                }
+                qCount += (uint32_t)__popcll(am);
             }
         }
-        (void)blkMask;
-
-        // ---- flush this tile's aborted tuples to the deferred queue ----
-        unsigned int myOff = 0;
-        if (nd) myOff = atomicAdd(&sDefCount, (unsigned int)nd);
-        __syncthreads();
-        const unsigned int tileDef = sDefCount;
-        if (tileDef) {
-            if (threadIdx.x == 0) sDefBase = atomicAdd(queueCount, (unsigned long long)tileDef);
-            __syncthreads();
-            const unsigned long long base = sDefBase;
-            for (int d = 0; d < nd; ++d) {
-                queue[base + myOff + d].pos = dpos[d];
-                queue[base + myOff + d].packed = dval[d];
-            }
-            deferred += nd;
-            __syncthreads();
-            if (threadIdx.x == 0) sDefCount = 0;
-        }
-        // (the next tile's first barrier orders the reset)
+        while (qCount) retry_round();     // drain before the window may slide
     }
 
     // ---- retire what is left of the window ----
@@ -240,7 +358,7 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
     if (haveWin) {
         for (uint32_t r = 0; r < kWinBlocks; ++r) {
             const uint32_t blk = wb + r, ring = blk & (kWinBlocks - 1);
-            if (blk < numBlocks && owned[ring]) {
+            if (blk < numBlocks && owned[ring] == 1) {
                 ulonglong2* dst = reinterpret_cast<ulonglong2*>(table + ((uint64_t)blk << kBlkShift));
                 const ulonglong2* src = reinterpret_cast<const ulonglong2*>(win + ((uint64_t)ring << kBlkShift));
                 for (uint32_t v = threadIdx.x; v < kBlkSlots / 2; v += kOwnThreads) dst[v] = src[v];
@@ -248,20 +366,21 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
         }
     }
     // counters: one atomic per wavefront
+    unsigned long long c0 = drops, c3 = bad, c4 = deferred;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        drops += __shfl_down(drops, off, 64);
+        c0 += __shfl_down(c0, off, 64);
         dropSum += __shfl_down(dropSum, off, 64);
         inSum += __shfl_down(inSum, off, 64);
-        bad += __shfl_down(bad, off, 64);
-        deferred += __shfl_down(deferred, off, 64);
+        c3 += __shfl_down(c3, off, 64);
+        c4 += __shfl_down(c4, off, 64);
     }
-    if ((threadIdx.x & 63) == 0) {
-        if (drops) atomicAdd(&ctr->conflicts, drops);
+    if (lane == 0) {
+        if (c0) atomicAdd(&ctr->conflicts, c0);
         if (dropSum) atomicAdd(&ctr->conflictSum, dropSum);
         if (inSum) atomicAdd(&ctr->inputSum, inSum);
-        if (bad) atomicAdd(&ctr->badKeys, bad);
-        if (deferred) atomicAdd(&ctr->spare[0], deferred);
+        if (c3) atomicAdd(&ctr->badKeys, c3);
+        if (c4) atomicAdd(&ctr->spare[0], c4);
     }
 }
 
@@ -287,7 +406,8 @@ k_clear_unowned(uint64_t* __restrict__ table, const unsigned int* __restrict__ o
 // Phase B: finish the probe walk of every deferred tuple with global atomics.
 __global__ void __launch_bounds__(kBlock)
 k_build_deferred(const DeferredEntry* __restrict__ queue, const unsigned long long* __restrict__ queueCount,
-                 uint64_t* __restrict__ table, uint64_t mask, uint32_t probeLen, Counters* __restrict__ ctr)
+                 uint64_t* __restrict__ table, uint64_t mask, uint64_t keyMask, uint32_t probeLen,
+                 Counters* __restrict__ ctr)
 {
     const unsigned long long nq = *queueCount;
     unsigned long long drops = 0, dropSum = 0;
@@ -295,16 +415,16 @@ k_build_deferred(const DeferredEntry* __restrict__ queue, const unsigned long lo
          i += (unsigned long long)gridDim.x * kBlock) {
         uint64_t mine = queue[i].packed;
         uint64_t pos = queue[i].pos;
-        const uint64_t home0 = (uint32_t)mine & mask;
+        const uint64_t home0 = (mine & keyMask) & mask;
         uint32_t budget = probeLen - (uint32_t)((pos - home0) & mask);
         for (;;) {
-            if (budget == 0) { drops += 1; dropSum += (uint32_t)mine; break; }
+            if (budget == 0) { drops += 1; dropSum += mine & keyMask; break; }
             const unsigned long long old =
                 atomicMin(reinterpret_cast<unsigned long long*>(table + pos), (unsigned long long)mine);
             if (old == kEmpty || old == mine) break;
             if (old > mine) {
                 mine = old;
-                const uint64_t home = (uint32_t)old & mask;
+                const uint64_t home = (old & keyMask) & mask;
                 budget = probeLen - ((uint32_t)((pos - home) & mask) + 1);
             } else {
                 budget -= 1;
@@ -327,7 +447,7 @@ k_build_deferred(const DeferredEntry* __restrict__ queue, const unsigned long lo
 // radix join, HTMHashBuild.hpp:100-154): over nSample tiles spread across R, count
 // the tiles whose home-slot span fits the LDS window.
 __global__ void __launch_bounds__(kBlock)
-k_sample_locality(const uint64_t* __restrict__ R, uint64_t n, uint64_t mask, uint32_t nSample,
+k_sample_locality(const uint64_t* __restrict__ R, uint64_t n, uint64_t mask, uint64_t keyMask, uint32_t nSample,
                   unsigned int* __restrict__ fitCount)
 {
     __shared__ unsigned long long sMin, sMax;
@@ -339,7 +459,7 @@ k_sample_locality(const uint64_t* __restrict__ R, uint64_t n, uint64_t mask, uin
         __syncthreads();
         unsigned long long lo = ~0ull, hi = 0;
         for (uint64_t i = b + threadIdx.x; i < e; i += kBlock) {
-            const unsigned long long h = R[i] & mask;
+            const unsigned long long h = (R[i] & keyMask) & mask;
             lo = h < lo ? h : lo; hi = h > hi ? h : hi;
         }
         if (lo != ~0ull) { atomicMin(&sMin, lo); atomicMax(&sMax, hi); }
@@ -357,24 +477,27 @@ size_t own_queue_bytes(uint64_t rSize) { return (rSize + 64) * sizeof(DeferredEn
 size_t own_owner_bytes(uint64_t tableSize) { return ((tableSize >> kBlkShift) + 1) * sizeof(unsigned int); }
 bool own_supported(uint64_t tableSize) { return tableSize >= (uint64_t)kWinSlots; }
 
-void launch_sample_locality(const uint64_t* R, uint64_t n, uint64_t tableSize, uint32_t nSample,
+void launch_sample_locality(const uint64_t* R, uint64_t n, uint64_t tableSize, uint32_t keyBits, uint32_t nSample,
                             unsigned int* fitCount, hipStream_t s)
 {
     (void)hipMemsetAsync(fitCount, 0, sizeof(unsigned int), s);
     hipLaunchKernelGGL(k_sample_locality, dim3(nSample < 256 ? nSample : 256), dim3(kBlock), 0, s,
-                       R, n, tableSize - 1, nSample, fitCount);
+                       R, n, tableSize - 1, (1ull << keyBits) - 1, nSample, fitCount);
 }
 
-void launch_build_own(const uint64_t* R, uint64_t n, uint64_t* table, uint64_t tableSize, uint32_t probeLen,
-                      uint64_t idxBase, void* ownerBuf, void* queueBuf, unsigned long long* queueCount,
-                      Counters* ctr, hipEvent_t evPhaseA, hipStream_t s)
+void launch_build_own(const uint64_t* R, uint64_t n, bool packed, uint32_t keyBits, uint64_t* table,
+                      uint64_t tableSize, uint32_t probeLen, uint64_t idxBase, void* ownerBuf, void* queueBuf,
+                      unsigned long long* queueCount, Counters* ctr, hipEvent_t evPhaseA, hipStream_t s)
 {
     static bool attrSet = false;
     if (!attrSet) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t));
         attrSet = true;
     }
+    const uint64_t keyMask = (1ull << keyBits) - 1;
     const uint32_t numBlocks = (uint32_t)(tableSize >> kBlkShift);
     (void)hipMemsetAsync(ownerBuf, 0, own_owner_bytes(tableSize), s);
     (void)hipMemsetAsync(queueCount, 0, sizeof(unsigned long long), s);
@@ -383,14 +506,32 @@ void launch_build_own(const uint64_t* R, uint64_t n, uint64_t* table, uint64_t t
     chunkLen = (chunkLen + kOwnTile - 1) / kOwnTile * kOwnTile;
     if (chunkLen < (uint64_t)kOwnTile * 4) chunkLen = (uint64_t)kOwnTile * 4;
     const unsigned grid = (unsigned)((n + chunkLen - 1) / chunkLen);
-    hipLaunchKernelGGL(k_build_own, dim3(grid), dim3(kOwnThreads), kWinSlots * sizeof(uint64_t), s,
-                       R, n, chunkLen, table, tableSize - 1, probeLen, idxBase,
-                       static_cast<unsigned int*>(ownerBuf), static_cast<DeferredEntry*>(queueBuf), queueCount, ctr);
+    if (packed)
+        hipLaunchKernelGGL(k_build_own<true>, dim3(grid), dim3(kOwnThreads), kWinSlots * sizeof(uint64_t), s,
+                           R, n, chunkLen, table, tableSize - 1, keyMask, probeLen, idxBase,
+                           static_cast<unsigned int*>(ownerBuf), static_cast<DeferredEntry*>(queueBuf), queueCount, ctr);
+    else {
+        // timing-only ablations (results wrong by construction), selected by HJ_OWN_ABLATE
+        static int abl = -1;
+        if (abl < 0) { const char* e = getenv("HJ_OWN_ABLATE"); abl = e ? atoi(e) : 0; }
+#define HJ_OWN_LAUNCH(A)                                                                                          \
+        hipLaunchKernelGGL((k_build_own<false, A>), dim3(grid), dim3(kOwnThreads), kWinSlots * sizeof(uint64_t), s, \
+                           R, n, chunkLen, table, tableSize - 1, keyMask, probeLen, idxBase,                         \
+                           static_cast<unsigned int*>(ownerBuf), static_cast<DeferredEntry*>(queueBuf), queueCount, ctr)
+        switch (abl) {
+            case 1: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(1); break;
+            case 2: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(2); break;
+            case 3: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(3); break;
+            case 7: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(7); break;
+            default: HJ_OWN_LAUNCH(0); break;
+        }
+#undef HJ_OWN_LAUNCH
+    }
     if (evPhaseA) (void)hipEventRecord(evPhaseA, s);
     hipLaunchKernelGGL(k_clear_unowned, dim3(2048), dim3(kBlock), 0, s, table,
                        static_cast<const unsigned int*>(ownerBuf), numBlocks, tableSize);
     hipLaunchKernelGGL(k_build_deferred, dim3(1024), dim3(kBlock), 0, s,
-                       static_cast<const DeferredEntry*>(queueBuf), queueCount, table, tableSize - 1, probeLen, ctr);
+                       static_cast<const DeferredEntry*>(queueBuf), queueCount, table, tableSize - 1, keyMask, probeLen, ctr);
 }
 
 }  // namespace hj

@@ -290,6 +290,17 @@ __device__ __forceinline__ uint32_t next_pow2_u32(uint32_t v)
     return v;
 }
 
+// Slot of key-remainder k in the LDS table. NOT the identity: inside a partition the remainders of
+// dense keys are consecutive integers, which under linear probing form one solid run that every
+// probe would have to walk to its end (measured: 2.4 s instead of milliseconds at 2^30). A
+// Fibonacci multiplicative hash scatters them; the reference avoids the issue with chained buckets
+// (bucket_chaining_join :247-252), whose idx = k & (N-1) is still what prjChecksum sums.
+__device__ __forceinline__ uint32_t join_hash(uint32_t k)
+{
+    return (k * 0x9E3779B1u) >> (32 - 15);   // kJoinSlots = 2^15
+}
+static_assert(kJoinSlots == (1u << 15), "join_hash assumes 2^15 slots");
+
 __global__ void __launch_bounds__(kJoinThreads)
 k_prj_join(const uint64_t* __restrict__ partR, const uint32_t* __restrict__ offR,
            const uint64_t* __restrict__ partS, const uint32_t* __restrict__ offS,
@@ -311,13 +322,13 @@ k_prj_join(const uint64_t* __restrict__ partR, const uint32_t* __restrict__ offR
         for (uint32_t i = blk + threadIdx.x; i < bend; i += kJoinThreads) {
             const uint32_t k = (uint32_t)partR[i] >> radixBits;  // distinguishes keys inside a partition
             checksum += k & idxMask;                              // :249,256
-            uint32_t h = k & (kJoinSlots - 1);
+            uint32_t h = join_hash(k);
             while (atomicCAS(&tab[h], kEmpty32, k) != kEmpty32) h = (h + 1) & (kJoinSlots - 1);
         }
         __syncthreads();
         for (uint32_t i = sb + threadIdx.x; i < se; i += kJoinThreads) {
             const uint32_t k = (uint32_t)partS[i] >> radixBits;
-            uint32_t h = k & (kJoinSlots - 1);
+            uint32_t h = join_hash(k);
             for (;;) {
                 const uint32_t v = tab[h];
                 if (v == kEmpty32) break;

@@ -129,18 +129,33 @@ class HashJoinContext:
         self._check(lib.hj_export_table(self._h, out.ctypes.data, tableSize))
         return out
 
+    # ---- raw device memory (hosts without a HIP runtime of their own) -------
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p()
+        self._check(lib.hj_dev_alloc(self._h, nbytes, C.byref(p)))
+        return p.value
+
+    def dev_free(self, ptr):
+        self._check(lib.hj_dev_free(self._h, C.c_void_p(ptr)))
+
+    def copy_h2d(self, dst_ptr, src_np):
+        src_np = np.ascontiguousarray(src_np)
+        self._check(lib.hj_copy_h2d(self._h, C.c_void_p(dst_ptr), src_np.ctypes.data, src_np.nbytes))
+
+    def copy_d2h(self, dst_np, src_ptr):
+        self._check(lib.hj_copy_d2h(self._h, dst_np.ctypes.data, C.c_void_p(src_ptr), dst_np.nbytes))
+
     def shard_histogram(self, d_in, n, n_shards, mode, table_size, d_counts):
         self._check(lib.hj_shard_histogram_dev(self._h, C.c_void_p(d_in), n, n_shards, mode, table_size,
                                                C.c_void_p(d_counts)))
 
-    def shard_scatter(self, d_in, n, n_shards, mode, table_size, d_counts, pack_idx_base, d_out):
+    def shard_scatter(self, d_in, n, n_shards, mode, table_size, d_counts, pack_idx_base, strip_bits, d_out):
         base = 0xFFFFFFFFFFFFFFFF if pack_idx_base is None else pack_idx_base
         self._check(lib.hj_shard_scatter_dev(self._h, C.c_void_p(d_in), n, n_shards, mode, table_size,
-                                             C.c_void_p(d_counts), base, C.c_void_p(d_out)))
+                                             C.c_void_p(d_counts), base, strip_bits, C.c_void_p(d_out)))
 
-    def build_packed(self, d_packed, n, global_table_size, slot_base, slice_slots):
-        self._check(lib.hj_build_packed_dev(self._h, C.c_void_p(d_packed), n, global_table_size,
-                                            slot_base, slice_slots))
+    def build_packed(self, d_packed, n, key_bits, table_size):
+        self._check(lib.hj_build_packed_dev(self._h, C.c_void_p(d_packed), n, key_bits, table_size))
 
 
 def _operator(algo, relR, rSize, relS, sSize, device, **kw):

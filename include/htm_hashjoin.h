@@ -160,20 +160,23 @@ int hj_export_table(hj_ctx *ctx, uint64_t *host_table, uint64_t tableSize);
 int hj_shard_histogram_dev(hj_ctx *ctx, const uint64_t *dIn, uint64_t n,
                            uint32_t nShards, uint32_t mode, uint64_t tableSize,
                            uint64_t *dCounts);
-/* Stable-by-destination scatter of dIn into dOut (both n tuples) using the
- * exclusive prefix of dCounts as bases. If packIdxBase != UINT64_MAX each
- * output tuple is (globalIdx << 32 | key) with globalIdx = packIdxBase + i, so
- * that index priority survives the exchange. Async. */
+/* Scatter of dIn into dOut (both n tuples) grouped by destination, using the
+ * exclusive prefix of dCounts as bases (order inside a destination is not
+ * defined). Each output tuple loses its low stripBits key bits (the shard
+ * number, when sharding by radix): key' = key >> stripBits. With
+ * packIdxBase == UINT64_MAX the output tuple is key'; otherwise it is
+ * ((packIdxBase + i) << (32 - stripBits)) | key', i.e. the tuple's global input
+ * index travels with it so that index priority survives the exchange. Async. */
 int hj_shard_scatter_dev(hj_ctx *ctx, const uint64_t *dIn, uint64_t n,
                          uint32_t nShards, uint32_t mode, uint64_t tableSize,
                          const uint64_t *dCounts, uint64_t packIdxBase,
-                         uint64_t *dOut);
-/* Like hj_build_dev but the tuples are already (globalIdx << 32 | key) and the
- * table is the slice [slotBase, slotBase+sliceSlots) of a global table of
- * globalTableSize slots. */
+                         uint32_t stripBits, uint64_t *dOut);
+/* Like hj_build_dev for tuples that are already (globalIdx << keyBits | key')
+ * (the output of hj_shard_scatter_dev after the exchange), into a table of
+ * tableSize slots (power of two, reserved via hj_reserve(tableSize/2)).
+ * hj_probe_dev then takes plain key' tuples. */
 int hj_build_packed_dev(hj_ctx *ctx, const uint64_t *dPacked, uint64_t n,
-                        uint64_t globalTableSize, uint64_t slotBase,
-                        uint64_t sliceSlots);
+                        uint32_t keyBits, uint64_t tableSize);
 
 /* ---- device memory for hosts without a HIP runtime of their own ----------- */
 int hj_dev_alloc(hj_ctx *ctx, uint64_t bytes, void **dptr);

@@ -43,7 +43,7 @@ def test_build_probe_matches_sequential_oracle(ctx, dist, window, n, variant):
     check_oa(got, want)
     assert got["buildVariant"] == (variant if n >= 4096 else 1)
     if variant == 2 and n >= 4096 and dist in ("sorted", "uniform") :
-        assert got["buildDeferred"] < n // 8          # locality: the LDS window takes almost everything
+        assert got["buildDeferred"] < n // 16         # locality: the LDS window takes almost everything
     # the whole table, slot for slot, equals the table a single thread builds in input order
     assert np.array_equal(ctx.export_table(2 * n), want["table"])
 
@@ -87,23 +87,28 @@ def test_auto_variant_follows_locality(ctx):
 
 
 def test_unaligned_device_pointers(ctx):
-    """R and S handed over at an odd tuple offset (8-byte, not 16-byte aligned)."""
-    import torch
+    """R and S handed over at an odd tuple offset (8-byte, not 16-byte aligned), through the
+    split device-pointer API (hj_reserve / hj_build_dev / hj_probe_dev / hj_fetch_result)."""
     n = 1 << 16
     R = oracle.generate_data("uniform", n, n, 16)
     S = oracle.generate_data("sorted", n)
     want = oracle.build_probe_seq(R, S, 4, want_table=True)
-    dR = torch.zeros(n + 1, dtype=torch.int64, device="cuda"); dR[1:] = torch.from_numpy(R.view("int64")).cuda()
-    dS = torch.zeros(n + 1, dtype=torch.int64, device="cuda"); dS[1:] = torch.from_numpy(S.view("int64")).cuda()
     for variant in (1, 2):
         with hj.HashJoinContext(0) as c2:
+            dR = c2.dev_alloc((n + 2) * 8)
+            dS = c2.dev_alloc((n + 2) * 8)
+            c2.copy_h2d(dR + 8, R)
+            c2.copy_h2d(dS + 8, S)
             c2.reserve("atomic", n, n, buildVariant=variant)
-            c2.build(dR.data_ptr() + 8, n)
-            c2.probe(dS.data_ptr() + 8, n)
+            c2.build(dR + 8, n)
+            c2.probe(dS + 8, n)
             c2.checksums()
             got = c2.fetch()
             check_oa(got, want)
+            assert got["buildVariant"] == variant
             assert np.array_equal(c2.export_table(2 * n), want["table"])
+            c2.dev_free(dR)
+            c2.dev_free(dS)
 
 
 def test_heavy_duplicates_and_tiny_sizes(ctx):
