@@ -27,7 +27,7 @@ struct hj_ctx {
     uint64_t* table = nullptr;
     uint64_t tableCapSlots = 0;   // allocated slots incl. slack
     uint64_t tableSize = 0;       // live table (2*rSize) of the last build
-    uint32_t keyBits = 32;        // low bits of a slot that hold the key
+    uint32_t homeShift = 0;       // home slot = (key >> homeShift) & (tableSize-1)
     uint64_t rSize = 0, sSize = 0;
     bool built = false;
     // ownership build (variant 2)
@@ -257,11 +257,11 @@ int hj_reserve(hj_ctx* c, const hj_params* params, uint64_t rSize, uint64_t sSiz
 }
 
 // Shared by hj_build_dev (DataGen tuples) and hj_build_packed_dev (index-packed tuples).
-static int build_common(hj_ctx* c, const uint64_t* d, uint64_t n, bool packed, uint32_t keyBits,
+static int build_common(hj_ctx* c, const uint64_t* d, uint64_t n, bool packed, uint32_t homeShift,
                         uint64_t tableSize, uint64_t idxBase)
 {
     HJ_HIP(c, hipSetDevice(c->device));
-    c->rSize = n; c->sSize = 0; c->tableSize = tableSize; c->keyBits = keyBits;
+    c->rSize = n; c->sSize = 0; c->tableSize = tableSize; c->homeShift = homeShift;
     for (bool& b : c->evSet) b = false;
     c->prjRan = false;
     HJ_HIP(c, hipMemsetAsync(c->dCtr, 0, sizeof(Counters), c->stream));
@@ -277,7 +277,7 @@ static int build_common(hj_ctx* c, const uint64_t* d, uint64_t n, bool packed, u
         if (canOwn && n) {
             // locality pre-round: 256 sample tiles; take the LDS-window kernel if >= 7/8 of them fit
             const uint32_t nSample = 256;
-            launch_sample_locality(d, n, tableSize, keyBits, nSample, c->fitCount, c->stream);
+            launch_sample_locality(d, n, tableSize, homeShift, nSample, c->fitCount, c->stream);
             HJ_HIP(c, hipMemcpyAsync(c->hFit, c->fitCount, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
             HJ_HIP(c, hipStreamSynchronize(c->stream));
             if (*c->hFit * 8 >= nSample * 7) variant = 2;
@@ -286,13 +286,13 @@ static int build_common(hj_ctx* c, const uint64_t* d, uint64_t n, bool packed, u
     c->variantUsed = variant;
     if (variant == 2) {
         if ((rc = record(c, EV_BUILD0))) return rc;
-        launch_build_own(d, n, packed, keyBits, c->table, tableSize, probe_len(c->params), idxBase, c->ownerBuf,
+        launch_build_own(d, n, packed, homeShift, c->table, tableSize, probe_len(c->params), idxBase, c->ownerBuf,
                          c->queueBuf, c->queueCount, c->dCtr, c->ev[EV_BUILD_A], c->stream);
         c->evSet[EV_BUILD_A] = true;
     } else {
         launch_fill_empty(c->table, tableSize + kTableSlack, c->stream);
         if ((rc = record(c, EV_BUILD0))) return rc;
-        if (packed) { if (n) launch_build_packed(d, n, c->table, tableSize, keyBits, probe_len(c->params), c->dCtr, c->stream); }
+        if (packed) { if (n) launch_build_packed(d, n, c->table, tableSize, homeShift, probe_len(c->params), c->dCtr, c->stream); }
         else launch_build_atomic_min(d, n, c->table, tableSize, probe_len(c->params), idxBase, c->dCtr, c->stream);
     }
     if ((rc = record(c, EV_BUILD1))) return rc;
@@ -308,17 +308,17 @@ int hj_build_dev(hj_ctx* c, const uint64_t* dR, uint64_t rSize, uint64_t idxBase
     if (!is_pow2(rSize) || 2 * rSize + kTableSlack > c->tableCapSlots)
         return fail(c, HJ_ERR_STATE, "hj_build_dev: hj_reserve() not called for this rSize");
     if (idxBase + rSize > (1ull << 32)) return fail(c, HJ_ERR_INVALID, "hj_build_dev: index range exceeds 32 bits");
-    return build_common(c, dR, rSize, false, 32, 2 * rSize, idxBase);
+    return build_common(c, dR, rSize, false, 0, 2 * rSize, idxBase);
 }
 
-int hj_build_packed_dev(hj_ctx* c, const uint64_t* dPacked, uint64_t n, uint32_t keyBits, uint64_t tableSize)
+int hj_build_packed_dev(hj_ctx* c, const uint64_t* dPacked, uint64_t n, uint32_t homeShift, uint64_t tableSize)
 {
     if (!c || (!dPacked && n)) return HJ_ERR_INVALID;
     if (c->params.algo == HJ_ALGO_PRJ) return fail(c, HJ_ERR_STATE, "hj_build_packed_dev: context is reserved for PRJ");
-    if (keyBits < 1 || keyBits > 32) return fail(c, HJ_ERR_INVALID, "hj_build_packed_dev: keyBits must be in [1,32]");
+    if (homeShift > 16) return fail(c, HJ_ERR_INVALID, "hj_build_packed_dev: homeShift must be in [0,16]");
     if (!is_pow2(tableSize) || tableSize + kTableSlack > c->tableCapSlots)
         return fail(c, HJ_ERR_STATE, "hj_build_packed_dev: hj_reserve() not called for this table size");
-    return build_common(c, dPacked, n, true, keyBits, tableSize, 0);
+    return build_common(c, dPacked, n, true, homeShift, tableSize, 0);
 }
 
 int hj_probe_dev(hj_ctx* c, const uint64_t* dS, uint64_t sSize)
@@ -328,7 +328,7 @@ int hj_probe_dev(hj_ctx* c, const uint64_t* dS, uint64_t sSize)
     HJ_HIP(c, hipSetDevice(c->device));
     int rc;
     if ((rc = record(c, EV_PROBE0))) return rc;
-    if (sSize) launch_probe(dS, sSize, c->table, c->tableSize, c->keyBits, probe_len(c->params), c->dCtr, c->stream);
+    if (sSize) launch_probe(dS, sSize, c->table, c->tableSize, c->homeShift, probe_len(c->params), c->dCtr, c->stream);
     if ((rc = record(c, EV_PROBE1))) return rc;
     HJ_HIP(c, hipGetLastError());
     c->sSize += sSize;
@@ -368,7 +368,7 @@ int hj_checksums_dev(hj_ctx* c)
     HJ_HIP(c, hipSetDevice(c->device));
     // zero the two sums so the call is idempotent
     HJ_HIP(c, hipMemsetAsync(&c->dCtr->tableSumHalf, 0, 2 * sizeof(unsigned long long), c->stream));
-    launch_table_sums(c->table, c->tableSize, c->tableSize / 2, c->keyBits, c->dCtr, c->stream);
+    launch_table_sums(c->table, c->tableSize, c->tableSize / 2, c->dCtr, c->stream);
     HJ_HIP(c, hipGetLastError());
     return HJ_OK;
 }
@@ -420,9 +420,8 @@ int hj_export_table(hj_ctx* c, uint64_t* host_table, uint64_t tableSize)
     HJ_HIP(c, hipMemcpyAsync(host_table, c->table, tableSize * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HJ_HIP(c, hipStreamSynchronize(c->stream));
     // device format (index << 32 | key, all ones = empty) -> reference format (key, 0 = empty)
-    const uint64_t keyMask = (1ull << c->keyBits) - 1;
     for (uint64_t i = 0; i < tableSize; ++i)
-        host_table[i] = host_table[i] == kEmpty ? 0 : (host_table[i] & keyMask);
+        host_table[i] = host_table[i] == kEmpty ? 0 : (uint32_t)host_table[i];
     return HJ_OK;
 }
 
@@ -465,19 +464,17 @@ int hj_shard_histogram_dev(hj_ctx* c, const uint64_t* dIn, uint64_t n, uint32_t 
 }
 
 int hj_shard_scatter_dev(hj_ctx* c, const uint64_t* dIn, uint64_t n, uint32_t nShards, uint32_t mode,
-                         uint64_t tableSize, const uint64_t* dCounts, uint64_t packIdxBase, uint32_t stripBits,
-                         uint64_t* dOut)
+                         uint64_t tableSize, const uint64_t* dCounts, uint64_t packIdxBase, uint64_t* dOut)
 {
     if (!c || (!dIn && n) || !dCounts || (!dOut && n)) return HJ_ERR_INVALID;
     if (!is_pow2(nShards) || nShards > 64 || mode > 1) return fail(c, HJ_ERR_INVALID, "hj_shard_scatter_dev: nShards must be a power of two <= 64");
     if (mode == 1 && (!is_pow2(tableSize) || tableSize < nShards)) return fail(c, HJ_ERR_INVALID, "hj_shard_scatter_dev: tableSize");
-    if (stripBits > 16) return fail(c, HJ_ERR_INVALID, "hj_shard_scatter_dev: stripBits");
-    if (packIdxBase != ~0ull && packIdxBase + n > (1ull << (32 + stripBits)))
-        return fail(c, HJ_ERR_INVALID, "hj_shard_scatter_dev: index range exceeds 32 + stripBits bits");
+    if (packIdxBase != ~0ull && packIdxBase + n > (1ull << 32))
+        return fail(c, HJ_ERR_INVALID, "hj_shard_scatter_dev: index range exceeds 32 bits");
     if (mode == 0) tableSize = 1ull << 32;
     HJ_HIP(c, hipSetDevice(c->device));
     launch_shard_scatter(dIn, n, nShards, mode, tableSize, reinterpret_cast<const unsigned long long*>(dCounts),
-                         c->shardCursors, packIdxBase, stripBits, dOut, c->stream);
+                         c->shardCursors, packIdxBase, dOut, c->stream);
     HJ_HIP(c, hipGetLastError());
     return HJ_OK;
 }

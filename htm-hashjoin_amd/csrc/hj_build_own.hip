@@ -70,7 +70,7 @@ constexpr int kQCap = 128;                        // per-wavefront retry queue e
 
 // owner[blk]: 0 = free, otherwise (workgroup id + 1).
 // PACKED = false: R holds DataGen tuples (value = key), index = idxBase + position.
-// PACKED = true : R holds (globalIdx << keyBits | key') from hj_shard_scatter_dev.
+// PACKED = true : R holds (globalIdx << 32 | key) from hj_shard_scatter_dev.
 //
 // rocprof showed the first versions VALU-issue bound (120 VALU + 90 SALU instructions per 64
 // tuples on unique keys, 5x that on duplicate-heavy `uniform`, LDS <10 % busy), so the insert is
@@ -86,7 +86,7 @@ constexpr int kQCap = 128;                        // per-wavefront retry queue e
 template <bool PACKED, int ABL = 0>
 __global__ void __launch_bounds__(kOwnThreads, 4)
 k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
-            uint64_t* __restrict__ table, uint64_t mask, uint64_t keyMask, uint32_t probeLen, uint64_t idxBase,
+            uint64_t* __restrict__ table, uint64_t mask, uint32_t homeShift, uint32_t probeLen, uint64_t idxBase,
             unsigned int* __restrict__ owner, DeferredEntry* __restrict__ queue,
             unsigned long long* __restrict__ queueCount, Counters* __restrict__ ctr)
 {
@@ -101,7 +101,6 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
     const uint64_t ce = (cb + chunkLen < n) ? cb + chunkLen : n;
     const uint32_t clen = (uint32_t)(ce - cb);                        // chunk length (< 2^32)
     const uint32_t mask32 = (uint32_t)mask;                           // tableSize <= 2^32 slots
-    const uint32_t kmask32 = (uint32_t)keyMask;
     const uint32_t numBlocks = (uint32_t)((mask + 1) >> kBlkShift);   // tableSize >= kWinSlots, host-checked
     const uint32_t me = blockIdx.x + 1;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -131,8 +130,8 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
         if (has) { pos = myQPos[qCount + lane]; mlo = myQLo[qCount + lane]; mhi = myQHi[qCount + lane]; }
         bool again = false, toDefer = false;
         if (has) {
-            const uint32_t key = PACKED ? (mlo & kmask32) : mlo;
-            uint32_t budget = probeLen - ((pos - (key & mask32)) & mask32);
+            const uint32_t key = mlo;
+            uint32_t budget = probeLen - ((pos - ((key >> homeShift) & mask32)) & mask32);
             const uint32_t blk = pos >> kBlkShift;
             if (budget == 0) {                                          // NoCCHashBuild.hpp:57-58
                 drops += 1; dropSum += key;
@@ -216,15 +215,15 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
             const bool in = full || (tb + tOff + 64 * j < clen);
             bool ok = in;
             if (PACKED) {
-                klo[j] = klo[j];                                         // key' = klo & kmask32 (keyBits <= 32)
-                if (in) inSum += klo[j] & kmask32;
+                if (in) inSum += klo[j];
+                if (in && klo[j] == 0) { bad += 1; ok = false; }
             } else {
                 if (in) inSum += pack64(khi[j], klo[j]);
                 if (in && (khi[j] != 0 || klo[j] == 0)) { bad += 1; ok = false; }
             }
             if (ok) {
                 liveMask |= 1u << j;
-                const uint32_t hb = ((PACKED ? (klo[j] & kmask32) : klo[j]) & mask32) >> kBlkShift;
+                const uint32_t hb = ((klo[j] >> homeShift) & mask32) >> kBlkShift;
                 myMin = hb < myMin ? hb : myMin;
             }
         }
@@ -273,7 +272,7 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
         if (haveWin) {
 #pragma unroll
             for (int j = 0; j < kPerThread; ++j) {
-                const uint32_t home = (PACKED ? (klo[j] & kmask32) : klo[j]) & mask32;
+                const uint32_t home = (klo[j] >> homeShift) & mask32;
                 const uint32_t hb = home >> kBlkShift;
                 const bool lv = (liveMask >> j) & 1u;
                 uint32_t r0 = (lv && hb - wb < kWinBlocks) ? (hb & (kWinBlocks - 1)) : 0xFFu;
@@ -327,7 +326,7 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
             const bool lv = (liveMask >> j) & 1u;
             uint32_t mlo = klo[j];
             uint32_t mhi = PACKED ? khi[j] : (idx0 + tb + tOff + 64 * j);
-            uint32_t pos = (PACKED ? (klo[j] & kmask32) : klo[j]) & mask32;
+            uint32_t pos = (klo[j] >> homeShift) & mask32;
             const uint32_t blk = pos >> kBlkShift;
             const bool own = lv && (blk - wb < kWinBlocks) && ((ownedMask >> (blk & (kWinBlocks - 1))) & 1u);
             bool again = lv && !own;                                    // not owned: the retry round defers it
@@ -406,7 +405,7 @@ k_clear_unowned(uint64_t* __restrict__ table, const unsigned int* __restrict__ o
 // Phase B: finish the probe walk of every deferred tuple with global atomics.
 __global__ void __launch_bounds__(kBlock)
 k_build_deferred(const DeferredEntry* __restrict__ queue, const unsigned long long* __restrict__ queueCount,
-                 uint64_t* __restrict__ table, uint64_t mask, uint64_t keyMask, uint32_t probeLen,
+                 uint64_t* __restrict__ table, uint64_t mask, uint32_t homeShift, uint32_t probeLen,
                  Counters* __restrict__ ctr)
 {
     const unsigned long long nq = *queueCount;
@@ -415,16 +414,16 @@ k_build_deferred(const DeferredEntry* __restrict__ queue, const unsigned long lo
          i += (unsigned long long)gridDim.x * kBlock) {
         uint64_t mine = queue[i].packed;
         uint64_t pos = queue[i].pos;
-        const uint64_t home0 = (mine & keyMask) & mask;
+        const uint64_t home0 = ((uint32_t)mine >> homeShift) & mask;
         uint32_t budget = probeLen - (uint32_t)((pos - home0) & mask);
         for (;;) {
-            if (budget == 0) { drops += 1; dropSum += mine & keyMask; break; }
+            if (budget == 0) { drops += 1; dropSum += (uint32_t)mine; break; }
             const unsigned long long old =
                 atomicMin(reinterpret_cast<unsigned long long*>(table + pos), (unsigned long long)mine);
             if (old == kEmpty || old == mine) break;
             if (old > mine) {
                 mine = old;
-                const uint64_t home = (old & keyMask) & mask;
+                const uint64_t home = ((uint32_t)old >> homeShift) & mask;
                 budget = probeLen - ((uint32_t)((pos - home) & mask) + 1);
             } else {
                 budget -= 1;
@@ -447,7 +446,7 @@ k_build_deferred(const DeferredEntry* __restrict__ queue, const unsigned long lo
 // radix join, HTMHashBuild.hpp:100-154): over nSample tiles spread across R, count
 // the tiles whose home-slot span fits the LDS window.
 __global__ void __launch_bounds__(kBlock)
-k_sample_locality(const uint64_t* __restrict__ R, uint64_t n, uint64_t mask, uint64_t keyMask, uint32_t nSample,
+k_sample_locality(const uint64_t* __restrict__ R, uint64_t n, uint64_t mask, uint32_t homeShift, uint32_t nSample,
                   unsigned int* __restrict__ fitCount)
 {
     __shared__ unsigned long long sMin, sMax;
@@ -459,7 +458,7 @@ k_sample_locality(const uint64_t* __restrict__ R, uint64_t n, uint64_t mask, uin
         __syncthreads();
         unsigned long long lo = ~0ull, hi = 0;
         for (uint64_t i = b + threadIdx.x; i < e; i += kBlock) {
-            const unsigned long long h = (R[i] & keyMask) & mask;
+            const unsigned long long h = ((uint32_t)R[i] >> homeShift) & mask;
             lo = h < lo ? h : lo; hi = h > hi ? h : hi;
         }
         if (lo != ~0ull) { atomicMin(&sMin, lo); atomicMax(&sMax, hi); }
@@ -477,15 +476,15 @@ size_t own_queue_bytes(uint64_t rSize) { return (rSize + 64) * sizeof(DeferredEn
 size_t own_owner_bytes(uint64_t tableSize) { return ((tableSize >> kBlkShift) + 1) * sizeof(unsigned int); }
 bool own_supported(uint64_t tableSize) { return tableSize >= (uint64_t)kWinSlots; }
 
-void launch_sample_locality(const uint64_t* R, uint64_t n, uint64_t tableSize, uint32_t keyBits, uint32_t nSample,
+void launch_sample_locality(const uint64_t* R, uint64_t n, uint64_t tableSize, uint32_t homeShift, uint32_t nSample,
                             unsigned int* fitCount, hipStream_t s)
 {
     (void)hipMemsetAsync(fitCount, 0, sizeof(unsigned int), s);
     hipLaunchKernelGGL(k_sample_locality, dim3(nSample < 256 ? nSample : 256), dim3(kBlock), 0, s,
-                       R, n, tableSize - 1, (1ull << keyBits) - 1, nSample, fitCount);
+                       R, n, tableSize - 1, homeShift, nSample, fitCount);
 }
 
-void launch_build_own(const uint64_t* R, uint64_t n, bool packed, uint32_t keyBits, uint64_t* table,
+void launch_build_own(const uint64_t* R, uint64_t n, bool packed, uint32_t homeShift, uint64_t* table,
                       uint64_t tableSize, uint32_t probeLen, uint64_t idxBase, void* ownerBuf, void* queueBuf,
                       unsigned long long* queueCount, Counters* ctr, hipEvent_t evPhaseA, hipStream_t s)
 {
@@ -497,7 +496,6 @@ void launch_build_own(const uint64_t* R, uint64_t n, bool packed, uint32_t keyBi
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t));
         attrSet = true;
     }
-    const uint64_t keyMask = (1ull << keyBits) - 1;
     const uint32_t numBlocks = (uint32_t)(tableSize >> kBlkShift);
     (void)hipMemsetAsync(ownerBuf, 0, own_owner_bytes(tableSize), s);
     (void)hipMemsetAsync(queueCount, 0, sizeof(unsigned long long), s);
@@ -508,7 +506,7 @@ void launch_build_own(const uint64_t* R, uint64_t n, bool packed, uint32_t keyBi
     const unsigned grid = (unsigned)((n + chunkLen - 1) / chunkLen);
     if (packed)
         hipLaunchKernelGGL(k_build_own<true>, dim3(grid), dim3(kOwnThreads), kWinSlots * sizeof(uint64_t), s,
-                           R, n, chunkLen, table, tableSize - 1, keyMask, probeLen, idxBase,
+                           R, n, chunkLen, table, tableSize - 1, homeShift, probeLen, idxBase,
                            static_cast<unsigned int*>(ownerBuf), static_cast<DeferredEntry*>(queueBuf), queueCount, ctr);
     else {
         // timing-only ablations (results wrong by construction), selected by HJ_OWN_ABLATE
@@ -516,7 +514,7 @@ void launch_build_own(const uint64_t* R, uint64_t n, bool packed, uint32_t keyBi
         if (abl < 0) { const char* e = getenv("HJ_OWN_ABLATE"); abl = e ? atoi(e) : 0; }
 #define HJ_OWN_LAUNCH(A)                                                                                          \
         hipLaunchKernelGGL((k_build_own<false, A>), dim3(grid), dim3(kOwnThreads), kWinSlots * sizeof(uint64_t), s, \
-                           R, n, chunkLen, table, tableSize - 1, keyMask, probeLen, idxBase,                         \
+                           R, n, chunkLen, table, tableSize - 1, homeShift, probeLen, idxBase,                         \
                            static_cast<unsigned int*>(ownerBuf), static_cast<DeferredEntry*>(queueBuf), queueCount, ctr)
         switch (abl) {
             case 1: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(1); break;
@@ -531,7 +529,7 @@ void launch_build_own(const uint64_t* R, uint64_t n, bool packed, uint32_t keyBi
     hipLaunchKernelGGL(k_clear_unowned, dim3(2048), dim3(kBlock), 0, s, table,
                        static_cast<const unsigned int*>(ownerBuf), numBlocks, tableSize);
     hipLaunchKernelGGL(k_build_deferred, dim3(1024), dim3(kBlock), 0, s,
-                       static_cast<const DeferredEntry*>(queueBuf), queueCount, table, tableSize - 1, keyMask, probeLen, ctr);
+                       static_cast<const DeferredEntry*>(queueBuf), queueCount, table, tableSize - 1, homeShift, probeLen, ctr);
 }
 
 }  // namespace hj

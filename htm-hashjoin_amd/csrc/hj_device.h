@@ -39,27 +39,26 @@ void launch_build_atomic_min(const uint64_t* R, uint64_t n, uint64_t* table,
                              uint64_t tableSize, uint32_t probeLen, uint64_t idxBase,
                              Counters* ctr, hipStream_t s);
 void launch_build_packed(const uint64_t* packed, uint64_t n, uint64_t* table, uint64_t tableSize,
-                         uint32_t keyBits, uint32_t probeLen, Counters* ctr, hipStream_t s);
+                         uint32_t homeShift, uint32_t probeLen, Counters* ctr, hipStream_t s);
 void launch_probe(const uint64_t* S, uint64_t n, const uint64_t* table, uint64_t tableSize,
-                  uint32_t keyBits, uint32_t probeLen, Counters* ctr, hipStream_t s);
-void launch_table_sums(const uint64_t* table, uint64_t tableSize, uint64_t halfSlots, uint32_t keyBits,
-                       Counters* ctr, hipStream_t s);
+                  uint32_t homeShift, uint32_t probeLen, Counters* ctr, hipStream_t s);
+void launch_table_sums(const uint64_t* table, uint64_t tableSize, uint64_t halfSlots, Counters* ctr,
+                       hipStream_t s);
 void launch_shard_histogram(const uint64_t* in, uint64_t n, uint32_t nShards, uint32_t mode,
                             uint64_t tableSize, unsigned long long* counts, hipStream_t s);
 void launch_shard_scatter(const uint64_t* in, uint64_t n, uint32_t nShards, uint32_t mode,
                           uint64_t tableSize, const unsigned long long* counts,
-                          unsigned long long* cursors, uint64_t packIdxBase, uint32_t stripBits,
-                          uint64_t* out, hipStream_t s);
+                          unsigned long long* cursors, uint64_t packIdxBase, uint64_t* out, hipStream_t s);
 
 // ---- ownership build (defined in hj_build_own.hip) ---------------------------
 size_t own_queue_bytes(uint64_t rSize);
 size_t own_owner_bytes(uint64_t tableSize);
 bool   own_supported(uint64_t tableSize);
-void launch_sample_locality(const uint64_t* R, uint64_t n, uint64_t tableSize, uint32_t keyBits, uint32_t nSample,
+void launch_sample_locality(const uint64_t* R, uint64_t n, uint64_t tableSize, uint32_t homeShift, uint32_t nSample,
                             unsigned int* fitCount, hipStream_t s);
 // phase A (LDS window) -> clear of unowned blocks -> phase B (deferred tuples).
 // Writes every table slot exactly once: no separate launch_fill_empty needed.
-void launch_build_own(const uint64_t* R, uint64_t n, bool packed, uint32_t keyBits, uint64_t* table,
+void launch_build_own(const uint64_t* R, uint64_t n, bool packed, uint32_t homeShift, uint64_t* table,
                       uint64_t tableSize, uint32_t probeLen, uint64_t idxBase, void* ownerBuf, void* queueBuf,
                       unsigned long long* queueCount, Counters* ctr, hipEvent_t evPhaseA, hipStream_t s);
 

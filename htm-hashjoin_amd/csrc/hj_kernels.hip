@@ -71,19 +71,20 @@ void launch_fill_empty(uint64_t* table, uint64_t nSlots, hipStream_t s)
 // ---------------------------------------------------------------------------
 // build
 // ---------------------------------------------------------------------------
-// Inserts `mine` = (index << keyBits | key) starting at slot `pos` with `budget`
-// probes left. keyMask = 2^keyBits - 1 (keyBits = 32 except for radix-sharded
-// input, where the shard bits are stripped from the key and given to the index);
-// homeMask = tableSize - 1.
+// Inserts `mine` = (index << 32 | key) starting at slot `pos` with `budget` probes
+// left. The home slot of a key is (key >> homeShift) & homeMask: homeShift is 0
+// except for radix-sharded input, where the low log2(shards) key bits are the same
+// for every tuple of a shard and are left out of the slot number; homeMask =
+// tableSize - 1.
 __device__ __forceinline__ void insert_priority(uint64_t* __restrict__ table, uint64_t homeMask,
-                                                uint64_t keyMask, uint32_t probeLen,
+                                                uint32_t homeShift, uint32_t probeLen,
                                                 uint64_t mine, uint64_t pos, uint32_t budget,
                                                 unsigned long long& drops, unsigned long long& dropSum)
 {
     for (;;) {
         if (budget == 0) {  // NoCCHashBuild.hpp:57-58
             drops += 1;
-            dropSum += mine & keyMask;
+            dropSum += (uint32_t)mine;
             return;
         }
         const unsigned long long old =
@@ -93,7 +94,7 @@ __device__ __forceinline__ void insert_priority(uint64_t* __restrict__ table, ui
             // displaced a later tuple: carry it on from the next slot with the
             // budget it has left there
             mine = old;
-            const uint64_t home = (old & keyMask) & homeMask;
+            const uint64_t home = ((uint32_t)old >> homeShift) & homeMask;
             const uint32_t disp = (uint32_t)((pos - home) & homeMask);
             budget = probeLen - (disp + 1);
         } else {
@@ -111,7 +112,7 @@ __device__ __forceinline__ void build_one(uint64_t t, uint64_t idx, uint64_t* __
     inSum += t;
     if ((t >> 32) != 0 || t == 0) { bad += 1; return; }
     const uint64_t mine = (idx << 32) | t;
-    insert_priority(table, mask, 0xFFFFFFFFull, probeLen, mine, t & mask, probeLen, drops, dropSum);
+    insert_priority(table, mask, 0, probeLen, mine, t & mask, probeLen, drops, dropSum);
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -147,18 +148,19 @@ void launch_build_atomic_min(const uint64_t* R, uint64_t n, uint64_t* table, uin
                        R, n, table, tableSize - 1, probeLen, idxBase, ctr);
 }
 
-// Build from pre-packed (globalIdx << keyBits | key') tuples (radix-sharded input: key' is the
-// key without its shard bits, hj_shard_scatter_dev). Same protocol, priority = global index.
+// Build from pre-packed (globalIdx << 32 | key) tuples (radix-sharded input after the
+// exchange, hj_shard_scatter_dev). Same protocol, priority = global index.
 __global__ void __launch_bounds__(kBlock)
 k_build_packed(const uint64_t* __restrict__ P, uint64_t n, uint64_t* __restrict__ table,
-               uint64_t homeMask, uint64_t keyMask, uint32_t probeLen, Counters* __restrict__ ctr)
+               uint64_t homeMask, uint32_t homeShift, uint32_t probeLen, Counters* __restrict__ ctr)
 {
     unsigned long long drops = 0, dropSum = 0, inSum = 0, bad = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
         const uint64_t p = P[i];
-        const uint64_t key = p & keyMask;
+        const uint32_t key = (uint32_t)p;
         inSum += key;
-        insert_priority(table, homeMask, keyMask, probeLen, p, key & homeMask, probeLen, drops, dropSum);
+        if (key == 0) { bad += 1; continue; }
+        insert_priority(table, homeMask, homeShift, probeLen, p, (key >> homeShift) & homeMask, probeLen, drops, dropSum);
     }
     flush_counter(&ctr->conflicts, drops);
     flush_counter(&ctr->conflictSum, dropSum);
@@ -167,34 +169,34 @@ k_build_packed(const uint64_t* __restrict__ P, uint64_t n, uint64_t* __restrict_
 }
 
 void launch_build_packed(const uint64_t* packed, uint64_t n, uint64_t* table, uint64_t tableSize,
-                         uint32_t keyBits, uint32_t probeLen, Counters* ctr, hipStream_t s)
+                         uint32_t homeShift, uint32_t probeLen, Counters* ctr, hipStream_t s)
 {
     hipLaunchKernelGGL(k_build_packed, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s,
-                       packed, n, table, tableSize - 1, (1ull << keyBits) - 1, probeLen, ctr);
+                       packed, n, table, tableSize - 1, homeShift, probeLen, ctr);
 }
 
 // ---------------------------------------------------------------------------
 // probe
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t probe_one(uint64_t sk, const uint64_t* __restrict__ table,
-                                              uint64_t mask, uint64_t keyMask, uint32_t probeLen)
+                                              uint64_t mask, uint32_t homeShift, uint32_t probeLen)
 {
     // NoCCHashBuild.hpp:70-79: walk at most probeLen consecutive slots from the
     // home slot, stop at the first empty one, count slots equal to the tuple.
-    const uint64_t* p = table + (sk & mask);
+    const uint64_t* p = table + ((sk >> homeShift) & mask);
     uint32_t m = 0;
     if (probeLen == 4) {
         const uint64_t a = p[0], b = p[1], c = p[2], d = p[3];  // slack slots make this safe
         const bool ea = a != kEmpty, eb = ea && b != kEmpty, ec = eb && c != kEmpty, ed = ec && d != kEmpty;
-        m += (ea && (a & keyMask) == sk);
-        m += (eb && (b & keyMask) == sk);
-        m += (ec && (c & keyMask) == sk);
-        m += (ed && (d & keyMask) == sk);
+        m += (ea && (uint64_t)(uint32_t)a == sk);
+        m += (eb && (uint64_t)(uint32_t)b == sk);
+        m += (ec && (uint64_t)(uint32_t)c == sk);
+        m += (ed && (uint64_t)(uint32_t)d == sk);
     } else {
         for (uint32_t j = 0; j < probeLen; ++j) {
             const uint64_t v = p[j];
             if (v == kEmpty) break;
-            m += ((v & keyMask) == sk);
+            m += ((uint64_t)(uint32_t)v == sk);
         }
     }
     return m;
@@ -202,7 +204,7 @@ __device__ __forceinline__ uint32_t probe_one(uint64_t sk, const uint64_t* __res
 
 __global__ void __launch_bounds__(kBlock)
 k_probe(const uint64_t* __restrict__ S, uint64_t n, const uint64_t* __restrict__ table, uint64_t mask,
-        uint64_t keyMask, uint32_t probeLen, Counters* __restrict__ ctr)
+        uint32_t homeShift, uint32_t probeLen, Counters* __restrict__ ctr)
 {
     unsigned long long matches = 0;
     const uint64_t head = (n > 0 && (reinterpret_cast<uintptr_t>(S) & 8)) ? 1 : 0;
@@ -210,29 +212,29 @@ k_probe(const uint64_t* __restrict__ S, uint64_t n, const uint64_t* __restrict__
     const uint64_t nv = (n - head) >> 1;
     for (uint64_t v = (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (uint64_t)gridDim.x * kBlock) {
         const ulonglong2 t = S2[v];
-        matches += probe_one(t.x, table, mask, keyMask, probeLen);
-        matches += probe_one(t.y, table, mask, keyMask, probeLen);
+        matches += probe_one(t.x, table, mask, homeShift, probeLen);
+        matches += probe_one(t.y, table, mask, homeShift, probeLen);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (head) matches += probe_one(S[0], table, mask, keyMask, probeLen);
+        if (head) matches += probe_one(S[0], table, mask, homeShift, probeLen);
         const uint64_t tail = head + 2 * nv;
-        if (tail < n) matches += probe_one(S[tail], table, mask, keyMask, probeLen);
+        if (tail < n) matches += probe_one(S[tail], table, mask, homeShift, probeLen);
     }
     flush_counter(&ctr->matches, matches);
 }
 
 void launch_probe(const uint64_t* S, uint64_t n, const uint64_t* table, uint64_t tableSize,
-                  uint32_t keyBits, uint32_t probeLen, Counters* ctr, hipStream_t s)
+                  uint32_t homeShift, uint32_t probeLen, Counters* ctr, hipStream_t s)
 {
     hipLaunchKernelGGL(k_probe, dim3(grid_for(n / 2 + 1, kBlock)), dim3(kBlock), 0, s,
-                       S, n, table, tableSize - 1, (1ull << keyBits) - 1, probeLen, ctr);
+                       S, n, table, tableSize - 1, homeShift, probeLen, ctr);
 }
 
 // ---------------------------------------------------------------------------
 // table checksums
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
-k_table_sums(const uint64_t* __restrict__ table, uint64_t tableSize, uint64_t halfSlots, uint64_t keyMask,
+k_table_sums(const uint64_t* __restrict__ table, uint64_t tableSize, uint64_t halfSlots,
              Counters* __restrict__ ctr)
 {
     unsigned long long half = 0, full = 0;
@@ -240,8 +242,8 @@ k_table_sums(const uint64_t* __restrict__ table, uint64_t tableSize, uint64_t ha
     const uint64_t nv = tableSize >> 1;  // tableSize = 2*rSize is even
     for (uint64_t v = (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (uint64_t)gridDim.x * kBlock) {
         const ulonglong2 t = t2[v];
-        const uint64_t a = (t.x == kEmpty) ? 0 : (t.x & keyMask);
-        const uint64_t b = (t.y == kEmpty) ? 0 : (t.y & keyMask);
+        const uint64_t a = (t.x == kEmpty) ? 0 : (uint32_t)t.x;
+        const uint64_t b = (t.y == kEmpty) ? 0 : (uint32_t)t.y;
         full += a + b;
         if (2 * v < halfSlots) half += a;
         if (2 * v + 1 < halfSlots) half += b;
@@ -250,11 +252,11 @@ k_table_sums(const uint64_t* __restrict__ table, uint64_t tableSize, uint64_t ha
     flush_counter(&ctr->tableSumFull, full);
 }
 
-void launch_table_sums(const uint64_t* table, uint64_t tableSize, uint64_t halfSlots, uint32_t keyBits,
-                       Counters* ctr, hipStream_t s)
+void launch_table_sums(const uint64_t* table, uint64_t tableSize, uint64_t halfSlots, Counters* ctr,
+                       hipStream_t s)
 {
     hipLaunchKernelGGL(k_table_sums, dim3(grid_for(tableSize / 2, kBlock * 4)), dim3(kBlock), 0, s,
-                       table, tableSize, halfSlots, (1ull << keyBits) - 1, ctr);
+                       table, tableSize, halfSlots, ctr);
 }
 
 // ---------------------------------------------------------------------------
@@ -295,7 +297,7 @@ k_shard_histogram(const uint64_t* __restrict__ in, uint64_t n, uint32_t nShards,
 __global__ void __launch_bounds__(kBlock)
 k_shard_scatter(const uint64_t* __restrict__ in, uint64_t n, uint32_t nShards, uint32_t mode,
                 uint64_t tableMask, uint32_t rangeShift, unsigned long long* __restrict__ cursors,
-                uint64_t packIdxBase, uint32_t stripBits, uint64_t* __restrict__ out)
+                uint64_t packIdxBase, uint64_t* __restrict__ out)
 {
     __shared__ unsigned int cnt[kShardMax];
     __shared__ unsigned long long base[kShardMax];
@@ -314,8 +316,7 @@ k_shard_scatter(const uint64_t* __restrict__ in, uint64_t n, uint32_t nShards, u
                 const uint64_t t = in[i];
                 d[k] = shard_of(t, shardMask, mode, tableMask, rangeShift);
                 r[k] = atomicAdd(&cnt[d[k]], 1u);
-                v[k] = (packIdxBase == ~0ull) ? (t >> stripBits)
-                                             : (((packIdxBase + i) << (32 - stripBits)) | ((uint32_t)t >> stripBits));
+                v[k] = (packIdxBase == ~0ull) ? t : (((packIdxBase + i) << 32) | (uint32_t)t);
             }
         }
         __syncthreads();
@@ -352,13 +353,12 @@ void launch_shard_histogram(const uint64_t* in, uint64_t n, uint32_t nShards, ui
 
 void launch_shard_scatter(const uint64_t* in, uint64_t n, uint32_t nShards, uint32_t mode,
                           uint64_t tableSize, const unsigned long long* counts,
-                          unsigned long long* cursors, uint64_t packIdxBase, uint32_t stripBits,
-                          uint64_t* out, hipStream_t s)
+                          unsigned long long* cursors, uint64_t packIdxBase, uint64_t* out, hipStream_t s)
 {
     const uint32_t shift = log2u64(tableSize) - log2u64(nShards);
     hipLaunchKernelGGL(k_shard_prefix, dim3(1), dim3(64), 0, s, counts, nShards, cursors);
     hipLaunchKernelGGL(k_shard_scatter, dim3(grid_for(n, kBlock * kShardPerThread)), dim3(kBlock), 0, s,
-                       in, n, nShards, mode, tableSize - 1, shift, cursors, packIdxBase, stripBits, out);
+                       in, n, nShards, mode, tableSize - 1, shift, cursors, packIdxBase, out);
 }
 
 }  // namespace hj

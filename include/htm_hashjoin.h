@@ -161,22 +161,24 @@ int hj_shard_histogram_dev(hj_ctx *ctx, const uint64_t *dIn, uint64_t n,
                            uint32_t nShards, uint32_t mode, uint64_t tableSize,
                            uint64_t *dCounts);
 /* Scatter of dIn into dOut (both n tuples) grouped by destination, using the
- * exclusive prefix of dCounts as bases (order inside a destination is not
- * defined). Each output tuple loses its low stripBits key bits (the shard
- * number, when sharding by radix): key' = key >> stripBits. With
- * packIdxBase == UINT64_MAX the output tuple is key'; otherwise it is
- * ((packIdxBase + i) << (32 - stripBits)) | key', i.e. the tuple's global input
- * index travels with it so that index priority survives the exchange. Async. */
+ * exclusive prefix of dCounts as bases (the order inside a destination is not
+ * defined). With packIdxBase == UINT64_MAX tuples are copied unchanged;
+ * otherwise each output tuple is ((packIdxBase + i) << 32) | key, i.e. the
+ * tuple's global input index travels with it so that index priority survives
+ * the exchange (packIdxBase + n must fit 32 bits). Async. */
 int hj_shard_scatter_dev(hj_ctx *ctx, const uint64_t *dIn, uint64_t n,
                          uint32_t nShards, uint32_t mode, uint64_t tableSize,
                          const uint64_t *dCounts, uint64_t packIdxBase,
-                         uint32_t stripBits, uint64_t *dOut);
-/* Like hj_build_dev for tuples that are already (globalIdx << keyBits | key')
- * (the output of hj_shard_scatter_dev after the exchange), into a table of
- * tableSize slots (power of two, reserved via hj_reserve(tableSize/2)).
- * hj_probe_dev then takes plain key' tuples. */
+                         uint64_t *dOut);
+/* Like hj_build_dev for tuples that are already (globalIdx << 32 | key) (the
+ * output of hj_shard_scatter_dev after the exchange), into a table of tableSize
+ * slots (a power of two, reserved via hj_reserve(rSize = tableSize/2)). The home
+ * slot of a key is (key >> homeShift) & (tableSize-1): with radix sharding the
+ * low log2(nShards) key bits are equal for all tuples of a shard and are left
+ * out of the slot number. hj_probe_dev afterwards takes plain tuples (value = key)
+ * and uses the same homeShift. */
 int hj_build_packed_dev(hj_ctx *ctx, const uint64_t *dPacked, uint64_t n,
-                        uint32_t keyBits, uint64_t tableSize);
+                        uint32_t homeShift, uint64_t tableSize);
 
 /* ---- device memory for hosts without a HIP runtime of their own ----------- */
 int hj_dev_alloc(hj_ctx *ctx, uint64_t bytes, void **dptr);

@@ -153,8 +153,17 @@ int orc_build_probe_seq(const uint64_t *R, uint64_t rSize,
                         uint32_t probeLength, orc_result *res,
                         uint64_t *table_out)
 {
+    /* NoCCHashBuild.hpp:20: tableSize = rSize*2 */
+    return orc_build_probe_seq_ts(R, rSize, S, sSize, probeLength, rSize * 2, 0, res, table_out);
+}
+
+int orc_build_probe_seq_ts(const uint64_t *R, uint64_t rSize,
+                           const uint64_t *S, uint64_t sSize,
+                           uint32_t probeLength, uint64_t tableSize, uint32_t homeShift,
+                           orc_result *res, uint64_t *table_out)
+{
     memset(res, 0, sizeof(*res));
-    uint64_t tableSize = rSize * 2;             /* NoCCHashBuild.hpp:20 */
+    if (tableSize == 0 || (tableSize & (tableSize - 1))) return -1;
     uint64_t tableMask = tableSize - 1;         /* :36 */
     uint64_t *output = (uint64_t *)calloc(tableSize + ORC_SLACK, sizeof(uint64_t));
     if (!output) return -1;
@@ -162,7 +171,7 @@ int orc_build_probe_seq(const uint64_t *R, uint64_t rSize,
 
     double t0 = now_us();
     for (uint64_t i = 0; i < rSize; i++) {      /* :43-59 */
-        uint64_t curSlot = R[i] & tableMask;
+        uint64_t curSlot = (R[i] >> homeShift) & tableMask;
         uint32_t probeBudget = probeLength;
         while (probeBudget != 0) {
             if (output[curSlot] == 0) {
@@ -181,7 +190,7 @@ int orc_build_probe_seq(const uint64_t *R, uint64_t rSize,
     uint64_t matches = 0;
     if (S) {
         for (uint64_t i = 0; i < sSize; i++) {  /* :70-79 */
-            uint64_t curSlot = S[i] & tableMask;
+            uint64_t curSlot = (S[i] >> homeShift) & tableMask;
             uint32_t probeBudget = probeLength;
             while (probeBudget-- && output[curSlot] != 0) {
                 if (output[curSlot] == S[i]) { matches++; curSlot++; }
@@ -194,7 +203,7 @@ int orc_build_probe_seq(const uint64_t *R, uint64_t rSize,
 
     uint64_t inputSum = 0, half = 0, full = 0;
     for (uint64_t i = 0; i < rSize; i++) inputSum += R[i];     /* :85-92  */
-    for (uint64_t i = 0; i < rSize; i++) half += output[i];    /* :94-101 */
+    for (uint64_t i = 0; i < tableSize / 2; i++) half += output[i]; /* :94-101 (tableSize/2 == rSize there) */
     for (uint64_t i = 0; i < tableSize; i++) full += output[i];
 
     res->rSize = rSize; res->sSize = S ? sSize : 0; res->tableSize = tableSize;

@@ -79,6 +79,16 @@ int orc_build_probe_seq(const uint64_t *R, uint64_t rSize,
                         uint32_t probeLength, orc_result *res,
                         uint64_t *table_out);
 
+/* The same loop with the table size given explicitly (a power of two) and the home slot
+ * taken as (key >> homeShift) & (tableSize-1). Used for the radix-sharded multi-GPU
+ * semantics, where shard g builds a table of 2 * (total |R| / shards) slots over the
+ * tuples whose low log2(shards) key bits equal g; those bits carry no information inside
+ * a shard and are left out of the slot number (homeShift = log2(shards)). */
+int orc_build_probe_seq_ts(const uint64_t *R, uint64_t rSize,
+                           const uint64_t *S, uint64_t sSize,
+                           uint32_t probeLength, uint64_t tableSize, uint32_t homeShift,
+                           orc_result *res, uint64_t *table_out);
+
 /* Threaded port used ONLY as the timed CPU baseline ("port"): numPartitions
  * contiguous chunks pulled by nthreads pthreads, exactly the chunking of
  * parallel_for(blocked_range(0,rSize,rSize/numPartitions)).  atomic=0 -> the

@@ -25,6 +25,8 @@ def _load():
     lib.orc_generate_zipf.argtypes = [C.c_uint64, C.c_uint32, C.c_double, C.c_uint, C.c_void_p]
     lib.orc_build_probe_seq.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32,
                                         C.POINTER(OrcResult), C.c_void_p]
+    lib.orc_build_probe_seq_ts.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64,
+                                           C.c_uint32, C.POINTER(OrcResult), C.c_void_p]
     lib.orc_build_probe_mt.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32,
                                        C.c_int, C.c_int, C.POINTER(OrcResult)]
     lib.orc_prj_join.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32,
@@ -90,6 +92,40 @@ def build_probe_seq(relR, relS=None, probe_length=4, want_table=False):
     if want_table:
         d["table"] = table
     return d
+
+
+def build_probe_seq_ts(relR, relS, table_size, home_shift=0, probe_length=4, want_table=False):
+    """Sequential build+probe into a table of table_size slots (sharded semantics)."""
+    relR = np.ascontiguousarray(relR, dtype=np.uint64)
+    res = OrcResult()
+    table = np.empty(table_size, dtype=np.uint64) if want_table else None
+    s_ptr, s_n = (None, 0)
+    if relS is not None:
+        relS = np.ascontiguousarray(relS, dtype=np.uint64)
+        s_ptr, s_n = relS.ctypes.data, relS.size
+    rc = _lib.orc_build_probe_seq_ts(relR.ctypes.data, relR.size, s_ptr, s_n, probe_length, table_size, home_shift,
+                                     C.byref(res), table.ctypes.data if want_table else None)
+    assert rc == 0
+    d = res.as_dict()
+    if want_table:
+        d["table"] = table
+    return d
+
+
+def sharded_reference(relR, relS, n_shards, probe_length=4):
+    """What the radix-sharded join computes: shard g takes the tuples with key & (G-1) == g in global
+    input order and runs the sequential build+probe into a table of 2*|R|/G slots with home slot
+    (key >> log2 G) & mask; counters are summed over shards."""
+    strip = (n_shards - 1).bit_length()
+    table_size = 2 * relR.size // n_shards
+    tot = {"conflicts": 0, "totalMatches": 0, "inputSum": 0, "tableSumFull": 0, "conflictSum": 0}
+    for g in range(n_shards):
+        Rg = relR[(relR & np.uint64(n_shards - 1)) == g]
+        Sg = relS[(relS & np.uint64(n_shards - 1)) == g]
+        r = build_probe_seq_ts(Rg, Sg, table_size, strip, probe_length)
+        for k in tot:
+            tot[k] += r[k]
+    return tot
 
 
 def build_probe_mt(relR, relS, probe_length=4, num_partitions=64, nthreads=1, atomic=False):

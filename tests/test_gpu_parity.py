@@ -241,3 +241,61 @@ def test_config2_size_properties(ctx):
             0, n, 9007199321849856, outsum)
     got = ctx.run("prj", R, S, radixBits=14)
     assert got["totalMatches"] == n and got["prjChecksum"] == 549688705024            # motivation_log1:8
+
+
+# ---- radix-sharded path: every GPU kernel of htm_hashjoin_amd/sharded.py on one device ------------
+@pytest.mark.parametrize("G", [2, 8])
+@pytest.mark.parametrize("dist,window", [("uniform", 16), ("local_shuffle", 1024), ("random", 16)])
+@pytest.mark.parametrize("variant", [1, 2])
+def test_sharded_kernels_on_one_gpu(ctx, G, dist, window, variant):
+    """G ranks emulated in turn on one GPU: shard histogram + scatter (index packing) per source piece,
+    the all-to-all done on the host, then hj_build_packed_dev / hj_probe_dev per destination shard.
+    Totals must equal oracle.sharded_reference (sequential, global input order, per-shard tables)."""
+    n = 1 << 16
+    n_local = n // G
+    R = oracle.generate_data(dist, n, n, window)
+    S = oracle.relS_for(dist, R)
+    want = oracle.sharded_reference(R, S, G)
+    strip = G.bit_length() - 1
+    inbox_r = [[] for _ in range(G)]
+    inbox_s = [[] for _ in range(G)]
+    with hj.HashJoinContext(0) as c:
+        d_in = c.dev_alloc(n_local * 8); d_out = c.dev_alloc(n_local * 8); d_cnt = c.dev_alloc(G * 8)
+        for src in range(G):
+            for rel, inbox, base in ((R, inbox_r, src * n_local), (S, inbox_s, None)):
+                piece = rel[src * n_local:(src + 1) * n_local]
+                c.copy_h2d(d_in, piece)
+                c.shard_histogram(d_in, n_local, G, 0, 0, d_cnt)
+                c.shard_scatter(d_in, n_local, G, 0, 0, d_cnt, base, d_out)
+                cnt = np.empty(G, dtype=np.uint64); c.copy_d2h(cnt, d_cnt)
+                out = np.empty(n_local, dtype=np.uint64); c.copy_d2h(out, d_out)
+                assert np.array_equal(cnt, np.bincount((piece & np.uint64(G - 1)).astype(np.int64), minlength=G).astype(np.uint64))
+                off = 0
+                for g in range(G):
+                    seg = out[off:off + int(cnt[g])]; off += int(cnt[g])
+                    assert np.all((seg & np.uint64(G - 1)) == g)                   # grouped by destination
+                    if base is not None:                                           # index packed above the key
+                        assert np.array_equal(np.sort(seg >> np.uint64(32)),
+                                              base + np.nonzero((piece & np.uint64(G - 1)) == g)[0].astype(np.uint64))
+                    inbox[g].append(seg)
+        for p in (d_in, d_out, d_cnt):
+            c.dev_free(p)
+    tot = {k: 0 for k in ("conflicts", "totalMatches", "inputSum", "tableSumFull", "conflictSum")}
+    table_size = 2 * n_local
+    for g in range(G):
+        got_r = np.concatenate(inbox_r[g]); got_s = np.concatenate(inbox_s[g])
+        with hj.HashJoinContext(0) as c:
+            r = table_size // 2
+            while r < got_r.size:
+                r *= 2
+            c.reserve("atomic", r, got_s.size, buildVariant=variant)
+            d_r = c.dev_alloc(max(got_r.size, 1) * 8); d_s = c.dev_alloc(max(got_s.size, 1) * 8)
+            c.copy_h2d(d_r, got_r); c.copy_h2d(d_s, got_s)
+            c.build_packed(d_r, got_r.size, strip, table_size)
+            c.probe(d_s, got_s.size)
+            c.checksums()
+            res = c.fetch()
+            for k in tot:
+                tot[k] += res[k]
+            c.dev_free(d_r); c.dev_free(d_s)
+    assert tot == want

@@ -1,0 +1,128 @@
+"""The N > 1 path (htm_hashjoin_amd/sharded.py) under torch.distributed with the gloo backend on
+CPU, world_size 2 and 4. The sharding / exchange logic is the product's; the per-rank compute engine
+is replaced by an oracle-backed one (tests only) because there is no GPU here. The all-reduced
+totals must equal oracle.sharded_reference() on the concatenated input, bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import oracle
+
+
+class OracleShardEngine:
+    """CPU stand-in for HipShardEngine: same interface, numpy + the CPU oracle (TEST ONLY)."""
+
+    def __init__(self):
+        self._res = None
+
+    def empty(self, n):
+        return torch.empty(int(n), dtype=torch.int64)
+
+    def histogram(self, t, n_shards):
+        k = t.numpy().view(np.uint64)
+        return torch.from_numpy(np.bincount((k & np.uint64(n_shards - 1)).astype(np.int64), minlength=n_shards)).to(torch.int64)
+
+    def scatter(self, t, n_shards, counts, pack_idx_base):
+        k = t.numpy().view(np.uint64)
+        dest = (k & np.uint64(n_shards - 1)).astype(np.int64)
+        order = np.argsort(dest, kind="stable")[::1]
+        rng = np.random.default_rng(len(k))            # the product's order inside a destination is undefined:
+        for d in range(n_shards):                      # shuffle inside each destination to prove it does not matter
+            seg = np.nonzero(dest[order] == d)[0]
+            order[seg] = rng.permutation(order[seg])
+        kp = k.copy()
+        if pack_idx_base is not None:
+            idx = np.arange(len(k), dtype=np.uint64) + np.uint64(pack_idx_base)
+            kp = (idx << np.uint64(32)) | kp
+        return torch.from_numpy(kp[order].view(np.int64).copy())
+
+    def reserve(self, table_size, max_r, max_s):
+        pass
+
+    def build_probe(self, r_packed, home_shift, table_size, s_keys):
+        p = r_packed.numpy().view(np.uint64)
+        p = np.sort(p)                                  # global index is the high field: sort = global input order
+        keys = p & np.uint64(0xFFFFFFFF)
+        s = s_keys.numpy().view(np.uint64)
+        self._res = oracle.build_probe_seq_ts(keys, s, table_size, home_shift)
+
+    def finish(self):
+        r = dict(self._res)
+        r.update(buildVariant=0, buildDeferred=0, build_us=0.0, probe_us=0.0, clear_us=0.0)
+        return r
+
+    def sync(self):
+        pass
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, dist_name, window, n_local, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import htm_hashjoin_amd as hj
+    from htm_hashjoin_amd.sharded import ShardedJoin
+    n = n_local * world
+    R = hj.generate_data(dist_name, n, n, window)
+    S = hj.generate_data("sorted", n)
+    r_local = torch.from_numpy(R[rank * n_local:(rank + 1) * n_local].view(np.int64).copy())
+    s_local = torch.from_numpy(S[rank * n_local:(rank + 1) * n_local].view(np.int64).copy())
+    job = ShardedJoin(OracleShardEngine(), torch, dist, rank, world)
+    job.step(r_local, s_local, rank * n_local, 2 * n_local)
+    res = job.result()
+    if rank == 0:
+        out.put({k: res[k] for k in ("conflicts", "totalMatches", "inputSum", "tableSumFull", "conflictSum")})
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("dist_name,window", [("uniform", 16), ("local_shuffle", 1024), ("random", 16)])
+def test_sharded_join_matches_sharded_reference(world, dist_name, window):
+    n_local = 1 << 12
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, PORT[0], dist_name, window, n_local, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n = n_local * world
+    R = oracle.generate_data(dist_name, n, n, window)
+    S = oracle.generate_data("sorted", n)
+    want = oracle.sharded_reference(R, S, world)
+    assert got == want
+    if dist_name == "local_shuffle":
+        assert got["conflicts"] == 0 and got["totalMatches"] == n
+
+
+PORT = [0]
+
+
+@pytest.fixture(autouse=True)
+def _port():
+    PORT[0] = _free_port()
+    yield
+
+
+def test_single_rank_is_the_plain_operator():
+    """world == 1: no exchange, no stripped bits; totals equal the single-table oracle."""
+    from htm_hashjoin_amd.sharded import ShardedJoin
+    n = 1 << 12
+    R = oracle.generate_data("uniform", n, n, 16)
+    S = oracle.generate_data("sorted", n)
+    job = ShardedJoin(OracleShardEngine(), torch, None, 0, 1)
+    job.step(torch.from_numpy(R.view(np.int64).copy()), torch.from_numpy(S.view(np.int64).copy()), 0, 2 * n)
+    got = job.result()
+    want = oracle.build_probe_seq(R, S)
+    for k in ("conflicts", "totalMatches", "inputSum", "tableSumFull", "conflictSum"):
+        assert got[k] == want[k]
