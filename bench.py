@@ -79,7 +79,7 @@ def oa_leg(torch, hj, ctx, n, dist, window, steps, warmup, S_dev=None, variant=0
     if S_dev is None:
         S_dev = torch.arange(1, n + 1, dtype=torch.int64, device="cuda")   # generate_data("sorted"), main.cpp:93
     ctx.reserve("atomic", n, n, buildVariant=variant)
-    kernel_us = {"clear_us": [], "build_us": [], "probe_us": []}
+    kernel_us = {"clear_us": [], "build_us": [], "probe_us": [], "buildPhaseA_us": []}
 
     def step():
         ctx.build(R_dev.data_ptr(), n)
@@ -169,10 +169,12 @@ def main():
     import htm_hashjoin_amd as hj
 
     n = 1 << a.log2n
-    if world > 1:
+    if world > 1 or os.environ.get("HJ_BENCH_FORCE_SHARDED") == "1":   # the env var rehearses the N>1 code path on one GPU
         import torch.distributed as dist_mod
         from htm_hashjoin_amd import sharded
-        dist_mod.init_process_group("nccl")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist_mod.init_process_group("nccl", rank=rank, world_size=world)
         line = sharded.bench_sharded(a, torch, dist_mod, hj, rank, world, local_rank)
         if rank == 0:
             print(json.dumps(line), flush=True)
@@ -187,27 +189,32 @@ def main():
     # (8 read + 8 slot write), duration = HIP-event time of that launch
     ku = main_leg["kernel_us"]
     v2 = main_leg["buildVariant"] == 2
-    names = {"build_us": "k_build_own (+k_clear_unowned, k_build_deferred)" if v2 else "k_build_atomic_min",
-             "probe_us": "k_probe", "clear_us": "k_sample_locality" if v2 else "k_fill_empty"}
-    # algorithmic bytes per launch: build = R read 8 + slot write 8 per R tuple;
-    # probe = S read 8 + home-slot read 8 per S tuple; the table clear (16 B per R tuple: 2|R| slots)
-    # is a separate launch in variant 1 and folded into the build in variant 2 (each slot written once)
-    alg = {"build_us": 16.0 * n, "probe_us": 16.0 * n, "clear_us": 0.0 if v2 else 16.0 * n}
-    dominant = max(("build_us", "probe_us"), key=lambda k: ku[k])
-    achieved = alg[dominant] / (ku[dominant] * 1e-6) / 1e9
+    # Dominant kernel = the build. Variant 2: k_build_own (phase A) timed alone by its own HIP events
+    # (hj_result.buildPhaseA_us); build_us additionally covers k_clear_unowned + k_build_deferred.
+    # Algorithmic bytes per launch: build = R read 8 + slot write 8 = 16 B per R tuple;
+    # probe = S read 8 + home-slot read 8 = 16 B per S tuple; table clear = 16 B per R tuple (2|R| slots).
+    dom_name = "k_build_own" if v2 else "k_build_atomic_min"
+    dom_us = ku["buildPhaseA_us"] if v2 else ku["build_us"]
+    alg = 16.0 * n
+    achieved = alg / (dom_us * 1e-6) / 1e9
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
-        traffic = json.load(open(pmc)).get(names[dominant].split()[0])
-    step_bytes = 48.0 * n      # clear 16 + build 16 + probe 16 per tuple pair, either variant
-    roofline = {"bound": "hbm", "kernel": names[dominant],
+    if os.path.exists(pmc) and a.log2n == 30 and a.dist == "uniform":
+        traffic = json.load(open(pmc)).get(dom_name)      # HBM bytes per launch from rocprofv3 PMC passes (same command)
+    step_bytes = 48.0 * n      # clear 16 + build 16 + probe 16 per (R,S) tuple pair
+    roofline = {"bound": "hbm", "kernel": dom_name,
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic,
-                "algorithmic_bytes_per_launch": alg[dominant],
-                "kernel_us": ku,
-                "per_kernel_GBps": {k: (alg[k] / (ku[k] * 1e-6) / 1e9 if ku[k] > 0 else None) for k in ku},
-                "whole_step_GBps": step_bytes / (main_leg["ms_per_step"] * 1e-3) / 1e9,
-                "whole_step_frac": step_bytes / (main_leg["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+                "algorithmic_bytes_per_launch": alg, "launch_us": dom_us,
+                "other_kernels": {
+                    "build_group_us (k_build_own + k_clear_unowned + k_build_deferred)" if v2 else "k_fill_empty_us":
+                        ku["build_us"] if v2 else ku["clear_us"],
+                    "k_probe_us": ku["probe_us"], "k_probe_GBps": 16.0 * n / (ku["probe_us"] * 1e-6) / 1e9,
+                    "k_sample_locality_plus_readback_us": ku["clear_us"] if v2 else None},
+                "whole_step": {"algorithmic_bytes": step_bytes, "GBps": step_bytes / (main_leg["ms_per_step"] * 1e-3) / 1e9,
+                               "frac": step_bytes / (main_leg["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                               "frac_reference_accounting_16B_per_tuple_no_clear":
+                                   32.0 * n / (main_leg["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
 
     extra = {}
     if not a.no_extra:

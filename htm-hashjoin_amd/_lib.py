@@ -45,7 +45,7 @@ class hj_result(C.Structure):
         + [("radixBits", C.c_uint32), ("buildVariant", C.c_uint32)]
         + [(n, C.c_double) for n in (
             "clear_us", "build_us", "probe_us", "partition_us", "join_us", "total_us", "h2d_us")]
-        + [("buildDeferred", C.c_uint64), ("reserved", C.c_uint64 * 3)]
+        + [("buildDeferred", C.c_uint64), ("buildPhaseA_us", C.c_double), ("reserved", C.c_uint64 * 2)]
     )
 
     def as_dict(self):

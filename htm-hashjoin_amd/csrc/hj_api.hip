@@ -400,6 +400,7 @@ int hj_fetch_result(hj_ctx* c, hj_result* out)
         out->outputSum = (c->params.algo == HJ_ALGO_NOCC ? k.tableSumHalf : k.tableSumFull) + k.conflictSum;
         out->buildVariant = c->variantUsed;
         out->buildDeferred = k.spare[0];
+        out->buildPhaseA_us = elapsed_us(c, EV_BUILD0, EV_BUILD_A);
         out->clear_us = elapsed_us(c, EV_CLEAR0, EV_BUILD0);
         out->build_us = elapsed_us(c, EV_BUILD0, EV_BUILD1);
         out->probe_us = elapsed_us(c, EV_PROBE0, EV_PROBE1);

@@ -97,7 +97,10 @@ typedef struct {
                                  separately, never part of total_us)              */
     uint64_t buildDeferred;   /* buildVariant 2: tuples that left the LDS window and
                                  were finished by the global-atomic phase            */
-    uint64_t reserved[3];
+    double   buildPhaseA_us;  /* buildVariant 2: device time of k_build_own alone
+                                 (build_us also covers k_clear_unowned and
+                                 k_build_deferred)                                   */
+    uint64_t reserved[2];
 } hj_result;
 
 typedef struct hj_ctx hj_ctx;
