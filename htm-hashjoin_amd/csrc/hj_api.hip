@@ -291,6 +291,7 @@ static int build_common(hj_ctx* c, const uint64_t* d, uint64_t n, bool packed, u
         c->evSet[EV_BUILD_A] = true;
     } else {
         launch_fill_empty(c->table, tableSize + kTableSlack, c->stream);
+        launch_set_full_range(tableSize, c->dCtr, c->stream);
         if ((rc = record(c, EV_BUILD0))) return rc;
         if (packed) { if (n) launch_build_packed(d, n, c->table, tableSize, homeShift, probe_len(c->params), c->dCtr, c->stream); }
         else launch_build_atomic_min(d, n, c->table, tableSize, probe_len(c->params), idxBase, c->dCtr, c->stream);
@@ -399,7 +400,7 @@ int hj_fetch_result(hj_ctx* c, hj_result* out)
         out->tableSumFull = k.tableSumFull;
         out->outputSum = (c->params.algo == HJ_ALGO_NOCC ? k.tableSumHalf : k.tableSumFull) + k.conflictSum;
         out->buildVariant = c->variantUsed;
-        out->buildDeferred = k.spare[0];
+        out->buildDeferred = k.deferred;
         out->buildPhaseA_us = elapsed_us(c, EV_BUILD0, EV_BUILD_A);
         out->clear_us = elapsed_us(c, EV_CLEAR0, EV_BUILD0);
         out->build_us = elapsed_us(c, EV_BUILD0, EV_BUILD1);
@@ -421,8 +422,12 @@ int hj_export_table(hj_ctx* c, uint64_t* host_table, uint64_t tableSize)
     HJ_HIP(c, hipMemcpyAsync(host_table, c->table, tableSize * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HJ_HIP(c, hipStreamSynchronize(c->stream));
     // device format (index << 32 | key, all ones = empty) -> reference format (key, 0 = empty)
+    // only [validLo, validHiEx + 512) holds defined values (hj_device.h); the rest is empty by definition
+    Counters k;
+    HJ_HIP(c, hipMemcpy(&k, c->dCtr, sizeof(k), hipMemcpyDeviceToHost));
+    const uint64_t lo = k.validLo, hi = k.validHiEx + 512 < tableSize ? k.validHiEx + 512 : tableSize;
     for (uint64_t i = 0; i < tableSize; ++i)
-        host_table[i] = host_table[i] == kEmpty ? 0 : (uint32_t)host_table[i];
+        host_table[i] = (i < lo || i >= hi || host_table[i] == kEmpty) ? 0 : (uint32_t)host_table[i];
     return HJ_OK;
 }
 

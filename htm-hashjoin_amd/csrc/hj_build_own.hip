@@ -117,6 +117,7 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
     bool haveWin = false;            // false until the first tile with a valid tuple
     unsigned long long dropSum = 0, inSum = 0;
     uint32_t drops = 0, bad = 0, deferred = 0;
+    uint32_t usedLo = 0xFFFFFFFFu, usedHi1 = 0;   // blocks this thread claimed or deferred into
     uint32_t ownedMask = 0;          // bit r: ring block r is mine (refreshed per tile)
     uint32_t qCount = 0;             // entries in this wavefront's retry queue (wave-uniform)
 
@@ -174,6 +175,8 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
                 const unsigned long long at = base + __popcll(dm & ((1ull << lane) - 1ull));
                 queue[at].pos = pos; queue[at].packed = pack64(mhi, mlo);
                 deferred += 1;
+                const uint32_t db = pos >> kBlkShift;
+                usedLo = db < usedLo ? db : usedLo; usedHi1 = db + 1 > usedHi1 ? db + 1 : usedHi1;
             }
         }
         const unsigned long long am = __ballot(again);
@@ -311,6 +314,7 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
                     const uint32_t blk = wb + ((t - wb) & (kWinBlocks - 1));   // ring position -> block in [wb, wb+K)
                     if (ABL & 2) owned[t] = 1u;
                     else owned[t] = (blk < numBlocks && atomicCAS(&owner[blk], 0u, me) == 0u) ? 1u : 2u;
+                    if (owned[t] == 1u) { usedLo = blk < usedLo ? blk : usedLo; usedHi1 = blk + 1 > usedHi1 ? blk + 1 : usedHi1; }
                 }
             }
         }
@@ -374,26 +378,53 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
         c3 += __shfl_down(c3, off, 64);
         c4 += __shfl_down(c4, off, 64);
     }
+    // block range touched: min via max of the complement (counters start at 0)
+    uint32_t loInv = ~usedLo, hi1 = usedHi1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t a = __shfl_down(loInv, off, 64), b = __shfl_down(hi1, off, 64);
+        loInv = a > loInv ? a : loInv; hi1 = b > hi1 ? b : hi1;
+    }
     if (lane == 0) {
         if (c0) atomicAdd(&ctr->conflicts, c0);
         if (dropSum) atomicAdd(&ctr->conflictSum, dropSum);
         if (inSum) atomicAdd(&ctr->inputSum, inSum);
         if (c3) atomicAdd(&ctr->badKeys, c3);
-        if (c4) atomicAdd(&ctr->spare[0], c4);
+        if (c4) atomicAdd(&ctr->deferred, c4);
+        if (hi1) { atomicMax(&ctr->usedLoInv, (unsigned long long)loInv); atomicMax(&ctr->usedHi1, (unsigned long long)hi1); }
     }
 }
 
-// Blocks nobody claimed (and the slack past the table end) get the empty pattern.
+// After phase A: the valid slot range. Stored tuples end up in blocks [lo, hi+1] (a probe walk spills
+// at most probeLen-1 slots past a home slot), probes may read one block further, so blocks [lo, hi+2]
+// are given defined contents and home slots in [lo*512, (hi+2)*512) are probed. If that reaches the
+// table end (probe walks wrap there) the whole table is made valid.
+__global__ void k_finalize_range(Counters* __restrict__ ctr, uint32_t numBlocks, uint64_t tableSize)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const unsigned long long hi1 = ctr->usedHi1;
+    if (hi1 == 0) { ctr->validLo = 0; ctr->validHiEx = 0; return; }          // nothing inserted anywhere
+    const unsigned long long lo = (unsigned long long)(uint32_t)~(uint32_t)ctr->usedLoInv;
+    const unsigned long long hiEx = hi1 + 1;                                   // blocks [lo, hi+1] probed
+    if (hiEx + 1 >= numBlocks) { ctr->validLo = 0; ctr->validHiEx = tableSize; }
+    else { ctr->validLo = lo << kBlkShift; ctr->validHiEx = hiEx << kBlkShift; }
+}
+
+// Blocks of the valid range nobody claimed (and the slack past the table end) get the empty pattern.
+// Blocks outside [validLo, validHiEx + 512) are never read, so they are not written either.
 __global__ void __launch_bounds__(kBlock)
-k_clear_unowned(uint64_t* __restrict__ table, const unsigned int* __restrict__ owner, uint32_t numBlocks,
-                uint64_t tableSize)
+k_clear_unowned(uint64_t* __restrict__ table, const unsigned int* __restrict__ owner, const Counters* __restrict__ ctr,
+                uint32_t numBlocks, uint64_t tableSize)
 {
     const ulonglong2 e = make_ulonglong2(kEmpty, kEmpty);
+    const uint32_t b0 = (uint32_t)(ctr->validLo >> kBlkShift);
+    uint32_t b1 = (uint32_t)(ctr->validHiEx >> kBlkShift) + 1;     // exclusive; one block past the probed range
+    if (b1 > numBlocks) b1 = numBlocks;
     // one wavefront per block: 64 lanes x 16 B x 4 = 4 KiB
     const uint32_t wavesPerGrid = gridDim.x * (kBlock / 64);
     const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
-    for (uint32_t blk = wave; blk < numBlocks; blk += wavesPerGrid) {
+    for (uint32_t blk = b0 + wave; blk < b1; blk += wavesPerGrid) {
         if (owner[blk] != 0) continue;
         ulonglong2* dst = reinterpret_cast<ulonglong2*>(table + ((uint64_t)blk << kBlkShift));
 #pragma unroll
@@ -526,8 +557,9 @@ void launch_build_own(const uint64_t* R, uint64_t n, bool packed, uint32_t homeS
 #undef HJ_OWN_LAUNCH
     }
     if (evPhaseA) (void)hipEventRecord(evPhaseA, s);
+    hipLaunchKernelGGL(k_finalize_range, dim3(1), dim3(64), 0, s, ctr, numBlocks, tableSize);
     hipLaunchKernelGGL(k_clear_unowned, dim3(2048), dim3(kBlock), 0, s, table,
-                       static_cast<const unsigned int*>(ownerBuf), numBlocks, tableSize);
+                       static_cast<const unsigned int*>(ownerBuf), ctr, numBlocks, tableSize);
     hipLaunchKernelGGL(k_build_deferred, dim3(1024), dim3(kBlock), 0, s,
                        static_cast<const DeferredEntry*>(queueBuf), queueCount, table, tableSize - 1, homeShift, probeLen, ctr);
 }

@@ -30,7 +30,15 @@ struct Counters {
     unsigned long long prjMatches;
     unsigned long long prjChecksum;
     unsigned long long prjOverflowParts; // partitions joined in several LDS blocks
-    unsigned long long spare[6];
+    unsigned long long deferred;         // variant 2: tuples finished by the global-atomic phase
+    // Variant 2 touches only the table blocks some tuple can reach; everything else is neither cleared
+    // nor read. usedLoInv / usedHi1 collect (max of ~block) and (max of block+1) over claimed blocks
+    // and deferred targets; k_finalize_range turns them into the valid SLOT range
+    // [validLo, validHiEx): a home slot outside it cannot match anything (k_probe skips it), slots in
+    // [validLo, validHiEx + 512) hold defined values.
+    unsigned long long usedLoInv, usedHi1;
+    unsigned long long validLo, validHiEx;
+    unsigned long long spare[1];
 };
 
 // ---- launch wrappers (defined in hj_kernels.hip) ---------------------------
@@ -44,6 +52,8 @@ void launch_probe(const uint64_t* S, uint64_t n, const uint64_t* table, uint64_t
                   uint32_t homeShift, uint32_t probeLen, Counters* ctr, hipStream_t s);
 void launch_table_sums(const uint64_t* table, uint64_t tableSize, uint64_t halfSlots, Counters* ctr,
                        hipStream_t s);
+// Marks the whole table valid (variant 1 clears and may touch all of it).
+void launch_set_full_range(uint64_t tableSize, Counters* ctr, hipStream_t s);
 void launch_shard_histogram(const uint64_t* in, uint64_t n, uint32_t nShards, uint32_t mode,
                             uint64_t tableSize, unsigned long long* counts, hipStream_t s);
 void launch_shard_scatter(const uint64_t* in, uint64_t n, uint32_t nShards, uint32_t mode,

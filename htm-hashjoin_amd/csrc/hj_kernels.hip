@@ -179,11 +179,15 @@ void launch_build_packed(const uint64_t* packed, uint64_t n, uint64_t* table, ui
 // probe
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t probe_one(uint64_t sk, const uint64_t* __restrict__ table,
-                                              uint64_t mask, uint32_t homeShift, uint32_t probeLen)
+                                              uint64_t mask, uint32_t homeShift, uint32_t probeLen,
+                                              uint64_t validLo, uint64_t validHiEx)
 {
+    // outside the valid range no stored tuple can have this home slot (hj_device.h, Counters)
+    const uint64_t home = (sk >> homeShift) & mask;
+    if (home < validLo || home >= validHiEx) return 0;
     // NoCCHashBuild.hpp:70-79: walk at most probeLen consecutive slots from the
     // home slot, stop at the first empty one, count slots equal to the tuple.
-    const uint64_t* p = table + ((sk >> homeShift) & mask);
+    const uint64_t* p = table + home;
     uint32_t m = 0;
     if (probeLen == 4) {
         const uint64_t a = p[0], b = p[1], c = p[2], d = p[3];  // slack slots make this safe
@@ -207,18 +211,19 @@ k_probe(const uint64_t* __restrict__ S, uint64_t n, const uint64_t* __restrict__
         uint32_t homeShift, uint32_t probeLen, Counters* __restrict__ ctr)
 {
     unsigned long long matches = 0;
+    const uint64_t validLo = ctr->validLo, validHiEx = ctr->validHiEx;
     const uint64_t head = (n > 0 && (reinterpret_cast<uintptr_t>(S) & 8)) ? 1 : 0;
     const ulonglong2* S2 = reinterpret_cast<const ulonglong2*>(S + head);
     const uint64_t nv = (n - head) >> 1;
     for (uint64_t v = (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (uint64_t)gridDim.x * kBlock) {
         const ulonglong2 t = S2[v];
-        matches += probe_one(t.x, table, mask, homeShift, probeLen);
-        matches += probe_one(t.y, table, mask, homeShift, probeLen);
+        matches += probe_one(t.x, table, mask, homeShift, probeLen, validLo, validHiEx);
+        matches += probe_one(t.y, table, mask, homeShift, probeLen, validLo, validHiEx);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (head) matches += probe_one(S[0], table, mask, homeShift, probeLen);
+        if (head) matches += probe_one(S[0], table, mask, homeShift, probeLen, validLo, validHiEx);
         const uint64_t tail = head + 2 * nv;
-        if (tail < n) matches += probe_one(S[tail], table, mask, homeShift, probeLen);
+        if (tail < n) matches += probe_one(S[tail], table, mask, homeShift, probeLen, validLo, validHiEx);
     }
     flush_counter(&ctr->matches, matches);
 }
@@ -239,8 +244,12 @@ k_table_sums(const uint64_t* __restrict__ table, uint64_t tableSize, uint64_t ha
 {
     unsigned long long half = 0, full = 0;
     const ulonglong2* t2 = reinterpret_cast<const ulonglong2*>(table);
-    const uint64_t nv = tableSize >> 1;  // tableSize = 2*rSize is even
-    for (uint64_t v = (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (uint64_t)gridDim.x * kBlock) {
+    // only [validLo, validHiEx + 512) holds defined values; both bounds are even
+    const uint64_t lo = ctr->validLo;
+    uint64_t hi = ctr->validHiEx + 512;
+    if (hi > tableSize) hi = tableSize;
+    const uint64_t nv = hi >> 1;
+    for (uint64_t v = (lo >> 1) + (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (uint64_t)gridDim.x * kBlock) {
         const ulonglong2 t = t2[v];
         const uint64_t a = (t.x == kEmpty) ? 0 : (uint32_t)t.x;
         const uint64_t b = (t.y == kEmpty) ? 0 : (uint32_t)t.y;
@@ -257,6 +266,16 @@ void launch_table_sums(const uint64_t* table, uint64_t tableSize, uint64_t halfS
 {
     hipLaunchKernelGGL(k_table_sums, dim3(grid_for(tableSize / 2, kBlock * 4)), dim3(kBlock), 0, s,
                        table, tableSize, halfSlots, ctr);
+}
+
+__global__ void k_set_full_range(uint64_t tableSize, Counters* __restrict__ ctr)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) { ctr->validLo = 0; ctr->validHiEx = tableSize; }
+}
+
+void launch_set_full_range(uint64_t tableSize, Counters* ctr, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_set_full_range, dim3(1), dim3(64), 0, s, tableSize, ctr);
 }
 
 // ---------------------------------------------------------------------------
