@@ -530,8 +530,17 @@ void launch_build_own(const uint64_t* R, uint64_t n, bool packed, uint32_t homeS
     const uint32_t numBlocks = (uint32_t)(tableSize >> kBlkShift);
     (void)hipMemsetAsync(ownerBuf, 0, own_owner_bytes(tableSize), s);
     (void)hipMemsetAsync(queueCount, 0, sizeof(unsigned long long), s);
-    // chunks: ~1024 workgroups (2 resident per CU x 256 CUs x 2 rounds), whole tiles
-    uint64_t chunkLen = (n + 1023) / 1024;
+    // one chunk per resident workgroup (2 per CU: 76 KiB LDS each): a single wave of workgroups, no tail,
+    // and the fewest chunk seams (measured: 512 chunks beat 768/1024/2048/4096 on MI355X)
+    static int nChunks = -1;
+    if (nChunks < 0) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const char* e = getenv("HJ_OWN_CHUNKS");
+        nChunks = e ? atoi(e) : 2 * cus;
+        if (nChunks < 1) nChunks = 512;
+    }
+    uint64_t chunkLen = (n + nChunks - 1) / nChunks;
     chunkLen = (chunkLen + kOwnTile - 1) / kOwnTile * kOwnTile;
     if (chunkLen < (uint64_t)kOwnTile * 4) chunkLen = (uint64_t)kOwnTile * 4;
     const unsigned grid = (unsigned)((n + chunkLen - 1) / chunkLen);
