@@ -7,9 +7,10 @@ One "step" = one pass of the hot path over one batch: clear table -> build(R) ->
 with R and S already resident in HBM (DataGen inputs, generated on the host and copied
 in before the timed region). N=1 workload: |R| = |S| = 2^30 uint32-key tuples, `uniform`
 (BASELINE.json metric; configs[1]'s operator at the metric's size). For N > 1 (launched
-with torch.distributed.run, one rank per GPU) every rank holds its own 2^log2n-tuple
-shard of R and S ("weak" scaling); tuples are exchanged by key radix with one all-to-all
-per relation over RCCL and joined locally (htm_hashjoin_amd/sharded.py).
+with torch.distributed.run, one rank per GPU) the SAME total workload is split over the
+ranks ("strong" scaling: rank g holds the g-th 1/N piece of R and of S); tuples are
+exchanged by key radix with one all-to-all per relation over RCCL and joined locally
+(htm_hashjoin_amd/sharded.py).
 
 Rank 0 prints ONE JSON line. `value` = (|R|+|S|) summed over all ranks / max-over-ranks
 time, in Mtuples/s. Extra objects: `roofline` (dominant kernel, HIP-event timed on the

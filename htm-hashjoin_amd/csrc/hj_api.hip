@@ -50,8 +50,10 @@ struct hj_ctx {
     // staging for hj_run
     uint64_t *stageR = nullptr, *stageS = nullptr;
     uint64_t capStageR = 0, capStageS = 0;
-    // shard helper scratch
-    unsigned long long* shardCursors = nullptr;
+    // shard helper: up to 4 inputs may sit between their histogram and their scatter
+    struct ShardPlan { const uint64_t* in = nullptr; uint64_t n = 0; uint32_t nShards = 0; void* work = nullptr; size_t cap = 0; uint64_t stamp = 0; };
+    ShardPlan shard[4];
+    uint64_t shardStamp = 0;
     // timing
     hipEvent_t ev[EV_COUNT]{};
     bool evSet[EV_COUNT]{};
@@ -141,7 +143,6 @@ int create_common(int device, void* stream, bool own, hj_ctx** out)
     }
     bool ok = hipMalloc(reinterpret_cast<void**>(&c->dCtr), sizeof(Counters)) == hipSuccess &&
               hipHostMalloc(reinterpret_cast<void**>(&c->hCtr), sizeof(Counters)) == hipSuccess &&
-              hipMalloc(reinterpret_cast<void**>(&c->shardCursors), sizeof(unsigned long long) * 64) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&c->queueCount), sizeof(unsigned long long)) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&c->fitCount), sizeof(unsigned int)) == hipSuccess &&
               hipHostMalloc(reinterpret_cast<void**>(&c->hFit), sizeof(unsigned int)) == hipSuccess;
@@ -177,8 +178,9 @@ void hj_destroy(hj_ctx* c)
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream || !c->ownStream) hipStreamSynchronize(c->stream);
-    void* frees[] = {c->table, c->dCtr, c->tmpA, c->partR, c->partS, c->work, c->stageR, c->stageS, c->shardCursors,
-                     c->ownerBuf, c->queueBuf, c->queueCount, c->fitCount};
+    void* frees[] = {c->table, c->dCtr, c->tmpA, c->partR, c->partS, c->work, c->stageR, c->stageS,
+                     c->ownerBuf, c->queueBuf, c->queueCount, c->fitCount, c->shard[0].work, c->shard[1].work,
+                     c->shard[2].work, c->shard[3].work};
     for (void* p : frees) if (p) hipFree(p);
     if (c->hCtr) hipHostFree(c->hCtr);
     if (c->hFit) hipHostFree(c->hFit);
@@ -456,32 +458,52 @@ int hj_run(hj_ctx* c, const hj_params* params, const uint64_t* relR, uint64_t rS
 }
 
 // ---- shard helpers -----------------------------------------------------------
+static int shard_check(hj_ctx* c, const char* who, uint64_t n, uint32_t nShards, uint32_t mode)
+{
+    if (!is_pow2(nShards) || nShards > 64) return fail(c, HJ_ERR_INVALID, who);
+    if (mode != 0) return fail(c, HJ_ERR_INVALID, "shard helpers: only mode 0 (low key bits) is implemented");
+    if (n >= 0xFFFFFFFFull) return fail(c, HJ_ERR_INVALID, "shard helpers: n must be < 2^32");
+    return HJ_OK;
+}
+
 int hj_shard_histogram_dev(hj_ctx* c, const uint64_t* dIn, uint64_t n, uint32_t nShards, uint32_t mode,
-                           uint64_t tableSize, uint64_t* dCounts)
+                           uint64_t /*tableSize*/, uint64_t* dCounts)
 {
     if (!c || (!dIn && n) || !dCounts) return HJ_ERR_INVALID;
-    if (!is_pow2(nShards) || nShards > 64 || mode > 1) return fail(c, HJ_ERR_INVALID, "hj_shard_histogram_dev: nShards must be a power of two <= 64");
-    if (mode == 1 && (!is_pow2(tableSize) || tableSize < nShards)) return fail(c, HJ_ERR_INVALID, "hj_shard_histogram_dev: tableSize");
-    if (mode == 0) tableSize = 1ull << 32;
+    int rc = shard_check(c, "hj_shard_histogram_dev: nShards must be a power of two <= 64", n, nShards, mode);
+    if (rc) return rc;
     HJ_HIP(c, hipSetDevice(c->device));
-    launch_shard_histogram(dIn, n, nShards, mode, tableSize, reinterpret_cast<unsigned long long*>(dCounts), c->stream);
+    // reuse the slot of the same input, else the least recently used one
+    hj_ctx::ShardPlan* slot = &c->shard[0];
+    for (auto& sp : c->shard) if (sp.in == dIn && sp.n == n) { slot = &sp; break; } else if (sp.stamp < slot->stamp) slot = &sp;
+    const size_t need = shard_work_bytes(n, nShards);
+    if (need > slot->cap) {
+        HJ_HIP(c, hipStreamSynchronize(c->stream));
+        if (slot->work) { HJ_HIP(c, hipFree(slot->work)); slot->work = nullptr; slot->cap = 0; }
+        HJ_HIP(c, hipMalloc(&slot->work, need));
+        slot->cap = need;
+    }
+    slot->in = dIn; slot->n = n; slot->nShards = nShards; slot->stamp = ++c->shardStamp;
+    launch_shard_hist(dIn, n, nShards, slot->work, reinterpret_cast<unsigned long long*>(dCounts), c->stream);
     HJ_HIP(c, hipGetLastError());
     return HJ_OK;
 }
 
 int hj_shard_scatter_dev(hj_ctx* c, const uint64_t* dIn, uint64_t n, uint32_t nShards, uint32_t mode,
-                         uint64_t tableSize, const uint64_t* dCounts, uint64_t packIdxBase, uint64_t* dOut)
+                         uint64_t /*tableSize*/, const uint64_t* dCounts, uint64_t packIdxBase, uint64_t* dOut)
 {
     if (!c || (!dIn && n) || !dCounts || (!dOut && n)) return HJ_ERR_INVALID;
-    if (!is_pow2(nShards) || nShards > 64 || mode > 1) return fail(c, HJ_ERR_INVALID, "hj_shard_scatter_dev: nShards must be a power of two <= 64");
-    if (mode == 1 && (!is_pow2(tableSize) || tableSize < nShards)) return fail(c, HJ_ERR_INVALID, "hj_shard_scatter_dev: tableSize");
+    int rc = shard_check(c, "hj_shard_scatter_dev: nShards must be a power of two <= 64", n, nShards, mode);
+    if (rc) return rc;
     if (packIdxBase != ~0ull && packIdxBase + n > (1ull << 32))
         return fail(c, HJ_ERR_INVALID, "hj_shard_scatter_dev: index range exceeds 32 bits");
-    if (mode == 0) tableSize = 1ull << 32;
+    hj_ctx::ShardPlan* slot = nullptr;
+    for (auto& sp : c->shard) if (sp.in == dIn && sp.n == n && sp.nShards == nShards && sp.work) slot = &sp;
+    if (!slot) return fail(c, HJ_ERR_STATE, "hj_shard_scatter_dev: call hj_shard_histogram_dev on this input first");
     HJ_HIP(c, hipSetDevice(c->device));
-    launch_shard_scatter(dIn, n, nShards, mode, tableSize, reinterpret_cast<const unsigned long long*>(dCounts),
-                         c->shardCursors, packIdxBase, dOut, c->stream);
+    launch_shard_scatter_ordered(dIn, n, nShards, slot->work, packIdxBase, dOut, c->stream);
     HJ_HIP(c, hipGetLastError());
+    slot->in = nullptr;   // consumed
     return HJ_OK;
 }
 

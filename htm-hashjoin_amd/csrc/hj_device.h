@@ -54,11 +54,12 @@ void launch_table_sums(const uint64_t* table, uint64_t tableSize, uint64_t halfS
                        hipStream_t s);
 // Marks the whole table valid (variant 1 clears and may touch all of it).
 void launch_set_full_range(uint64_t tableSize, Counters* ctr, hipStream_t s);
-void launch_shard_histogram(const uint64_t* in, uint64_t n, uint32_t nShards, uint32_t mode,
-                            uint64_t tableSize, unsigned long long* counts, hipStream_t s);
-void launch_shard_scatter(const uint64_t* in, uint64_t n, uint32_t nShards, uint32_t mode,
-                          uint64_t tableSize, const unsigned long long* counts,
-                          unsigned long long* cursors, uint64_t packIdxBase, uint64_t* out, hipStream_t s);
+// multi-GPU destination split (defined in hj_prj.hip: one order-preserving radix pass)
+size_t shard_work_bytes(uint64_t n, uint32_t nShards);
+void launch_shard_hist(const uint64_t* in, uint64_t n, uint32_t nShards, void* work, unsigned long long* counts,
+                       hipStream_t s);
+void launch_shard_scatter_ordered(const uint64_t* in, uint64_t n, uint32_t nShards, void* work, uint64_t packIdxBase,
+                                  uint64_t* out, hipStream_t s);
 
 // ---- ownership build (defined in hj_build_own.hip) ---------------------------
 size_t own_queue_bytes(uint64_t rSize);

@@ -278,106 +278,4 @@ void launch_set_full_range(uint64_t tableSize, Counters* ctr, hipStream_t s)
     hipLaunchKernelGGL(k_set_full_range, dim3(1), dim3(64), 0, s, tableSize, ctr);
 }
 
-// ---------------------------------------------------------------------------
-// multi-GPU shard helpers
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t shard_of(uint64_t t, uint32_t shardMask, uint32_t mode,
-                                             uint64_t tableMask, uint32_t rangeShift)
-{
-    // mode 0: low key bits (HASH_BIT_MODULO, parallel_radix_join.c:59)
-    // mode 1: high bits of the home slot (keeps probe windows on one shard)
-    return mode == 0 ? ((uint32_t)t & shardMask) : (uint32_t)((t & tableMask) >> rangeShift);
-}
-
-constexpr int kShardMax = 64;
-constexpr int kShardPerThread = 8;
-
-__global__ void __launch_bounds__(kBlock)
-k_shard_histogram(const uint64_t* __restrict__ in, uint64_t n, uint32_t nShards, uint32_t mode,
-                  uint64_t tableMask, uint32_t rangeShift, unsigned long long* __restrict__ counts)
-{
-    __shared__ unsigned int h[kShardMax];
-    if (threadIdx.x < kShardMax) h[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t shardMask = nShards - 1;
-    // each block owns contiguous tiles so that per-block counts fit 32 bits
-    const uint64_t tile = (uint64_t)kBlock * kShardPerThread;
-    for (uint64_t base = (uint64_t)blockIdx.x * tile; base < n; base += (uint64_t)gridDim.x * tile) {
-#pragma unroll
-        for (int k = 0; k < kShardPerThread; ++k) {
-            const uint64_t i = base + (uint64_t)k * kBlock + threadIdx.x;
-            if (i < n) atomicAdd(&h[shard_of(in[i], shardMask, mode, tableMask, rangeShift)], 1u);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < nShards && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)h[threadIdx.x]);
-}
-
-__global__ void __launch_bounds__(kBlock)
-k_shard_scatter(const uint64_t* __restrict__ in, uint64_t n, uint32_t nShards, uint32_t mode,
-                uint64_t tableMask, uint32_t rangeShift, unsigned long long* __restrict__ cursors,
-                uint64_t packIdxBase, uint64_t* __restrict__ out)
-{
-    __shared__ unsigned int cnt[kShardMax];
-    __shared__ unsigned long long base[kShardMax];
-    const uint32_t shardMask = nShards - 1;
-    const uint64_t tile = (uint64_t)kBlock * kShardPerThread;
-    for (uint64_t t0 = (uint64_t)blockIdx.x * tile; t0 < n; t0 += (uint64_t)gridDim.x * tile) {
-        if (threadIdx.x < kShardMax) cnt[threadIdx.x] = 0;
-        __syncthreads();
-        uint64_t v[kShardPerThread];
-        uint32_t d[kShardPerThread], r[kShardPerThread];
-#pragma unroll
-        for (int k = 0; k < kShardPerThread; ++k) {
-            const uint64_t i = t0 + (uint64_t)k * kBlock + threadIdx.x;
-            d[k] = 0xFFFFFFFFu;
-            if (i < n) {
-                const uint64_t t = in[i];
-                d[k] = shard_of(t, shardMask, mode, tableMask, rangeShift);
-                r[k] = atomicAdd(&cnt[d[k]], 1u);
-                v[k] = (packIdxBase == ~0ull) ? t : (((packIdxBase + i) << 32) | (uint32_t)t);
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < nShards && cnt[threadIdx.x])
-            base[threadIdx.x] = atomicAdd(&cursors[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < kShardPerThread; ++k)
-            if (d[k] != 0xFFFFFFFFu) out[base[d[k]] + r[k]] = v[k];
-        __syncthreads();
-    }
-}
-
-// cursors[d] = exclusive prefix of counts (nShards <= 64: one wavefront)
-__global__ void k_shard_prefix(const unsigned long long* __restrict__ counts, uint32_t nShards,
-                               unsigned long long* __restrict__ cursors)
-{
-    if (threadIdx.x == 0) {
-        unsigned long long s = 0;
-        for (uint32_t d = 0; d < nShards; ++d) { cursors[d] = s; s += counts[d]; }
-    }
-}
-
-static uint32_t log2u64(uint64_t v) { uint32_t l = 0; while ((1ull << l) < v) ++l; return l; }
-
-void launch_shard_histogram(const uint64_t* in, uint64_t n, uint32_t nShards, uint32_t mode,
-                            uint64_t tableSize, unsigned long long* counts, hipStream_t s)
-{
-    hipMemsetAsync(counts, 0, sizeof(unsigned long long) * nShards, s);
-    const uint32_t shift = log2u64(tableSize) - log2u64(nShards);
-    hipLaunchKernelGGL(k_shard_histogram, dim3(grid_for(n, kBlock * kShardPerThread)), dim3(kBlock), 0, s,
-                       in, n, nShards, mode, tableSize - 1, shift, counts);
-}
-
-void launch_shard_scatter(const uint64_t* in, uint64_t n, uint32_t nShards, uint32_t mode,
-                          uint64_t tableSize, const unsigned long long* counts,
-                          unsigned long long* cursors, uint64_t packIdxBase, uint64_t* out, hipStream_t s)
-{
-    const uint32_t shift = log2u64(tableSize) - log2u64(nShards);
-    hipLaunchKernelGGL(k_shard_prefix, dim3(1), dim3(64), 0, s, counts, nShards, cursors);
-    hipLaunchKernelGGL(k_shard_scatter, dim3(grid_for(n, kBlock * kShardPerThread)), dim3(kBlock), 0, s,
-                       in, n, nShards, mode, tableSize - 1, shift, cursors, packIdxBase, out);
-}
-
 }  // namespace hj

@@ -40,6 +40,7 @@ struct PassParams {
     uint32_t chunkLen;          // multiple of kTile
     const uint32_t* chunkBase;  // [nSeg + 1] exclusive prefix of chunks per segment
     uint32_t shift, fan;        // bin = (key >> shift) & (fan - 1)
+    uint64_t packIdxBase;       // ~0: tuples move unchanged; else output = (packIdxBase + i) << 32 | key
 };
 
 // chunkBase[s] = sum_{t<s} ceil(len_t / chunkLen). nSeg <= 256: one thread.
@@ -241,6 +242,10 @@ k_radix_scatter(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, Pas
             const uint64_t i = tb + 2 * ((uint64_t)k * kBlock + threadIdx.x);
             ulonglong2 t = make_ulonglong2(0, 0);
             if (i < r.end) t = in2[i >> 1];
+            if (p.packIdxBase != ~0ull) {   // shard scatter: the input index travels above the key
+                t.x = ((p.packIdxBase + i) << 32) | (uint32_t)t.x;
+                t.y = ((p.packIdxBase + i + 1) << 32) | (uint32_t)t.y;
+            }
             tv[2 * k] = t.x; tv[2 * k + 1] = t.y;
             br[2 * k] = br[2 * k + 1] = 0xFFFFFFFFu;
             if (i >= r.begin && i < r.end) {
@@ -434,7 +439,7 @@ void run_pass(const uint64_t* in, uint64_t* out, uint64_t n, const uint32_t* seg
     const uint32_t fan = 1u << bits;
     const PassLayout l = pass_layout(n, nSeg, fan);
     hipLaunchKernelGGL(k_chunk_base, dim3(1), dim3(64), 0, s, segIn, nSeg, l.chunkLen, w.chunkBase);
-    PassParams p{segIn, nSeg, l.chunkLen, w.chunkBase, shift, fan};
+    PassParams p{segIn, nSeg, l.chunkLen, w.chunkBase, shift, fan, ~0ull};
     // entries past the live chunks must be zero for the scan to be a prefix of live data only
     hipMemsetAsync(w.hist, 0, sizeof(uint32_t) * l.histEntries, s);
     hipLaunchKernelGGL(k_radix_hist, dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s, in, p, w.hist);
@@ -476,6 +481,65 @@ void launch_prj(const PrjPlan& pl, const PrjBuffers& buf, const uint64_t* R, uin
     }
     hipLaunchKernelGGL(k_prj_join, dim3(P), dim3(kJoinThreads), kJoinSlots * sizeof(uint32_t), s,
                        buf.partR, w.offR, S ? buf.partS : nullptr, w.offS, pl.radixBits, ctr);
+}
+
+// ---------------------------------------------------------------------------
+// multi-GPU destination split (hj_shard_histogram_dev / hj_shard_scatter_dev): one radix pass on
+// the low log2(nShards) key bits. Chunk order is preserved (scan-based cursors, no atomics across
+// workgroups), so a near-sorted input stays near-sorted inside every destination and the receiving
+// rank's locality pre-round still picks the LDS-window build.
+// ---------------------------------------------------------------------------
+namespace {
+struct ShardWork { uint32_t *seg0, *segOut, *chunkBase, *hist, *sums; };
+ShardWork shard_carve(void* base, uint64_t n, uint32_t fan)
+{
+    const PassLayout l = pass_layout(n, 1, fan);
+    char* p = static_cast<char*>(base);
+    ShardWork w;
+    w.seg0 = reinterpret_cast<uint32_t*>(p); p += 256;
+    w.segOut = reinterpret_cast<uint32_t*>(p); p += align_up(sizeof(uint32_t) * (fan + 1), 256);
+    w.chunkBase = reinterpret_cast<uint32_t*>(p); p += 256;
+    w.hist = reinterpret_cast<uint32_t*>(p); p += align_up(sizeof(uint32_t) * l.histEntries, 256);
+    w.sums = reinterpret_cast<uint32_t*>(p);
+    return w;
+}
+__global__ void k_shard_counts(const uint32_t* __restrict__ segOut, uint32_t fan, unsigned long long* __restrict__ counts)
+{
+    if (threadIdx.x < fan) counts[threadIdx.x] = segOut[threadIdx.x + 1] - segOut[threadIdx.x];
+}
+}  // namespace
+
+size_t shard_work_bytes(uint64_t n, uint32_t nShards)
+{
+    const PassLayout l = pass_layout(n, 1, nShards);
+    return 256 + align_up(sizeof(uint32_t) * (nShards + 1), 256) + 256 +
+           align_up(sizeof(uint32_t) * l.histEntries, 256) + align_up(sizeof(uint32_t) * (l.scanBlocks + 1), 256);
+}
+
+void launch_shard_hist(const uint64_t* in, uint64_t n, uint32_t nShards, void* work, unsigned long long* counts,
+                       hipStream_t s)
+{
+    const ShardWork w = shard_carve(work, n, nShards);
+    const PassLayout l = pass_layout(n, 1, nShards);
+    hipLaunchKernelGGL(k_init_seg, dim3(1), dim3(64), 0, s, w.seg0, (uint32_t)n);
+    hipLaunchKernelGGL(k_chunk_base, dim3(1), dim3(64), 0, s, w.seg0, 1u, l.chunkLen, w.chunkBase);
+    PassParams p{w.seg0, 1u, l.chunkLen, w.chunkBase, 0u, nShards, ~0ull};
+    (void)hipMemsetAsync(w.hist, 0, sizeof(uint32_t) * l.histEntries, s);
+    hipLaunchKernelGGL(k_radix_hist, dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s, in, p, w.hist);
+    hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)l.scanBlocks), dim3(kBlock), 0, s, w.hist, l.histEntries, w.sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, s, w.sums, (uint32_t)l.scanBlocks);
+    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)l.scanBlocks), dim3(kBlock), 0, s, w.hist, l.histEntries, w.sums);
+    hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(kBlock), 0, s, p, w.hist, (uint32_t)n, w.segOut);
+    hipLaunchKernelGGL(k_shard_counts, dim3(1), dim3(64), 0, s, w.segOut, nShards, counts);
+}
+
+void launch_shard_scatter_ordered(const uint64_t* in, uint64_t n, uint32_t nShards, void* work, uint64_t packIdxBase,
+                                  uint64_t* out, hipStream_t s)
+{
+    const ShardWork w = shard_carve(work, n, nShards);
+    const PassLayout l = pass_layout(n, 1, nShards);
+    PassParams p{w.seg0, 1u, l.chunkLen, w.chunkBase, 0u, nShards, packIdxBase};
+    hipLaunchKernelGGL(k_radix_scatter, dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s, in, out, p, w.hist);
 }
 
 }  // namespace hj

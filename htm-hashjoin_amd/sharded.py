@@ -152,16 +152,21 @@ class ShardedJoin:
 
 
 def bench_sharded(args, torch, dist, hj, rank, world, local_rank):
-    """bench.py's N > 1 leg: weak scaling, 2^log2n tuples of R and of S per rank."""
-    n = 1 << args.log2n
+    """bench.py's N > 1 leg. STRONG scaling: the total stays the N=1 workload (|R| = |S| = 2^log2n tuples,
+    the metric's configuration), each rank holding a 1/N contiguous piece. (The global input index that
+    travels with every R tuple is 32 bits, so total |R| must stay below 2^32; weak scaling at 2^30 tuples
+    per GPU would need 33 bits at N = 8.)"""
     strip = _log2(world)
-    if args.log2n + strip > 31:
+    n_total = 1 << args.log2n
+    if args.log2n > 31:
         raise SystemExit("total |R| must stay below 2^32 tuples (32-bit global index)")
-    # rank g's shard = the g-th piece of a DataGen relation over the global key domain; every rank
-    # draws its piece with the same generator on its own key range [g*n+1, (g+1)*n]
+    n = n_total >> strip                            # per rank
+    # Rank g's piece = DataGen over its own key range [g*n+1, (g+1)*n]: globally this is the near-sorted
+    # relation the reference generates, drawn piecewise (a rank cannot afford the serial 2^30 rand() stream
+    # of its neighbours).
     window = args.shuffle_range
     R = hj.generate_data(args.dist, n, n, window)
-    R += np.uint64(rank * n)                       # shard g holds keys of its own range (near-sorted globally)
+    R += np.uint64(rank * n)
     r_local = torch.from_numpy(R.view("int64")).to(f"cuda:{local_rank}")
     del R
     s_local = torch.arange(rank * n + 1, (rank + 1) * n + 1, dtype=torch.int64, device=f"cuda:{local_rank}")
@@ -189,18 +194,20 @@ def bench_sharded(args, torch, dist, hj, rank, world, local_rank):
     line = {
         "metric": "Mtuples/sec build+probe, |R|=|S|=1B uint32, uniform vs local_shuffle",
         "value": total * args.steps / dt / 1e6, "unit": "Mtuples/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "u64 tuples (u32 key), integer",
         "data": "synthetic (DataGen restatement per rank on its own key range)",
-        "config": {"workload": f"radix-sharded open-addressing build+probe, {world} GPUs, per GPU |R|=|S|=2^{args.log2n}, "
-                               f"dataDistr={args.dist} W={window}; step = shard histogram + scatter + all-to-all "
-                               "(R and S) + local clear/build/probe", "algo": "atomic", "rSize": n * world,
+        "config": {"workload": f"radix-sharded open-addressing build+probe over {world} GPUs, total |R|=|S|=2^{args.log2n} "
+                               f"({n} per GPU), dataDistr={args.dist} W={window}; step = destination histogram + "
+                               "order-preserving scatter + all-to-all (R and S) + local table clear/build/probe + "
+                               "counter all-reduce", "algo": "atomic", "rSize": n * world,
                    "sSize": n * world, "per_gpu_rSize": n, "dataDistr": args.dist, "shuffleRange": window,
                    "parallelism": f"radix{world}"},
         "result": {k: res[k] for k in ("conflicts", "totalMatches", "inputSum", "buildDeferred")},
         "checks": {"matches_plus_conflicts_eq_rSize": res["totalMatches"] + res["conflicts"] == n * world,
                    "unique_keys_all_match": (res["totalMatches"] == n * world) if unique else None},
         "exchange": res["exchange"], "local_kernel_us": {k: res["local"][k] for k in ("clear_us", "build_us", "probe_us")},
+        "local_build_variant": res["local"]["buildVariant"],
         "roofline": None, "cpu_baseline": None,
     }
     eng.close()

@@ -156,16 +156,19 @@ int hj_fetch_result(hj_ctx *ctx, hj_result *out);
 int hj_export_table(hj_ctx *ctx, uint64_t *host_table, uint64_t tableSize);
 
 /* ---- multi-GPU sharding helpers (new design) ---------------- */
-/* dest(key) for `nShards` ranks. mode 0 = radix: low bits of the key
- * (HASH_BIT_MODULO, parallel_radix_join.c:59); mode 1 = range: high bits of the
- * home slot key&(tableSize-1), which keeps linear-probe neighbours together. */
-/* Counts tuples per destination: dCounts[nShards] (device, uint64). Async. */
+/* dest(key) = key & (nShards-1): the low key bits (HASH_BIT_MODULO,
+ * parallel_radix_join.c:59); nShards a power of two <= 64. `mode` must be 0 and
+ * `tableSize` is ignored (reserved for a range split). */
+/* Counts tuples per destination into dCounts[nShards] (device, uint64) and keeps
+ * the per-chunk write cursors for the scatter of the same input. Async. */
 int hj_shard_histogram_dev(hj_ctx *ctx, const uint64_t *dIn, uint64_t n,
                            uint32_t nShards, uint32_t mode, uint64_t tableSize,
                            uint64_t *dCounts);
-/* Scatter of dIn into dOut (both n tuples) grouped by destination, using the
- * exclusive prefix of dCounts as bases (the order inside a destination is not
- * defined). With packIdxBase == UINT64_MAX tuples are copied unchanged;
+/* Scatter of dIn into dOut (both n tuples) grouped by destination; must follow
+ * hj_shard_histogram_dev on the same (dIn, n). The input order is preserved
+ * chunk-wise inside every destination (scan-based cursors; only the 4096 tuples
+ * of a tile may be permuted among themselves), so near-sorted inputs stay
+ * near-sorted. With packIdxBase == UINT64_MAX tuples are copied unchanged;
  * otherwise each output tuple is ((packIdxBase + i) << 32) | key, i.e. the
  * tuple's global input index travels with it so that index priority survives
  * the exchange (packIdxBase + n must fit 32 bits). Async. */

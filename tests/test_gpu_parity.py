@@ -275,8 +275,11 @@ def test_sharded_kernels_on_one_gpu(ctx, G, dist, window, variant):
                     seg = out[off:off + int(cnt[g])]; off += int(cnt[g])
                     assert np.all((seg & np.uint64(G - 1)) == g)                   # grouped by destination
                     if base is not None:                                           # index packed above the key
-                        assert np.array_equal(np.sort(seg >> np.uint64(32)),
-                                              base + np.nonzero((piece & np.uint64(G - 1)) == g)[0].astype(np.uint64))
+                        idx = (seg >> np.uint64(32)).astype(np.int64)
+                        assert np.array_equal(np.sort(idx), base + np.nonzero((piece & np.uint64(G - 1)) == g)[0])
+                        # input order is preserved up to permutations inside one 4096-tuple tile
+                        if idx.size:
+                            assert np.all(idx - np.maximum.accumulate(idx) > -4096)
                     inbox[g].append(seg)
         for p in (d_in, d_out, d_cnt):
             c.dev_free(p)
