@@ -123,48 +123,46 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
 
     // One dense retry round over up to 64 queue entries (popped from the tail). Unfinished entries
     // are pushed back. Terminal events: placed, dropped (budget exhausted), deferred (block not owned).
+    // (written with flags and selects rather than nested branches: the first version of this kernel
+    //  spent as many SALU instructions on exec-mask bookkeeping as VALU instructions on tuples)
     auto retry_round = [&]() {
         const uint32_t take = qCount < 64u ? qCount : 64u;
         qCount -= take;
         const bool has = lane < take;
-        uint32_t pos = 0, mlo = 0, mhi = 0;
-        if (has) { pos = myQPos[qCount + lane]; mlo = myQLo[qCount + lane]; mhi = myQHi[qCount + lane]; }
-        bool again = false, toDefer = false;
-        if (has) {
-            const uint32_t key = mlo;
-            uint32_t budget = probeLen - ((pos - ((key >> homeShift) & mask32)) & mask32);
-            const uint32_t blk = pos >> kBlkShift;
-            if (budget == 0) {                                          // NoCCHashBuild.hpp:57-58
-                drops += 1; dropSum += key;
-            } else if (blk - wb >= kWinBlocks || !((ownedMask >> (blk & (kWinBlocks - 1))) & 1u)) {
-                toDefer = true;                                         // abort -> global deferred queue
-            } else {
-                const uint64_t mine = pack64(mhi, mlo);
-                uint32_t skip = 0;
-                if ((pos & (kBlkSlots - 1)) <= kBlkSlots - 4) {
-                    // the next 4 slots sit in this (owned) block: look before leaping. Slot values
-                    // only decrease, so a slot seen below `mine` stays below it.
-                    const uint64_t* w = &win[pos & (kWinSlots - 1)];
-                    const uint64_t v0 = w[0], v1 = w[1], v2 = w[2], v3 = w[3];
-                    if (v0 < mine) { skip = 1; if (v1 < mine) { skip = 2; if (v2 < mine) { skip = 3; if (v3 < mine) skip = 4; } } }
-                    skip = skip < budget ? skip : budget;
-                    pos = (pos + skip) & mask32; budget -= skip;
-                }
-                if (budget == 0) {
-                    drops += 1; dropSum += key;
-                } else if (skip == 4) {
-                    again = true;                                       // may have left the block: re-check next round
-                } else {
-                    const unsigned long long old =
-                        atomicMin(reinterpret_cast<unsigned long long*>(&win[pos & (kWinSlots - 1)]), (unsigned long long)mine);
-                    if (old != kEmpty && old != mine) {
-                        if (old > mine) { mlo = (uint32_t)old; mhi = (uint32_t)(old >> 32); }   // displaced: carry it on
-                        pos = (pos + 1) & mask32;
-                        again = true;
-                    }
-                }
-            }
-        }
+        // lanes >= take read stale-but-in-bounds queue entries (qCount + lane < kQCap) and ignore them
+        uint32_t pos = myQPos[qCount + lane], mlo = myQLo[qCount + lane], mhi = myQHi[qCount + lane];
+        const uint32_t key = mlo;
+        uint32_t budget = probeLen - ((pos - ((key >> homeShift) & mask32)) & mask32);
+        const uint32_t blk = pos >> kBlkShift;
+        const bool ownOk = (blk - wb < kWinBlocks) & (((ownedMask >> (blk & (kWinBlocks - 1))) & 1u) != 0);
+        const bool drop0 = has & (budget == 0);                           // NoCCHashBuild.hpp:57-58
+        const bool toDefer = has & !drop0 & !ownOk;                        // abort -> global deferred queue
+        const bool work = has & !drop0 & ownOk;
+        const uint64_t mine = pack64(mhi, mlo);
+        // look before leaping: read the next 4 slots when they sit in this (owned) block -- otherwise
+        // read the block's first 4 slots and ignore them. Slot values only decrease, so a slot seen
+        // below `mine` stays below it.
+        const bool inBlk = (pos & (kBlkSlots - 1)) <= kBlkSlots - 4;
+        const uint32_t rd = work ? (inBlk ? pos : (pos & ~(kBlkSlots - 1))) : 0u;
+        const uint64_t* w = &win[rd & (kWinSlots - 1)];
+        const uint64_t v0 = w[0], v1 = w[1], v2 = w[2], v3 = w[3];
+        const bool c0 = v0 < mine, c1 = c0 & (v1 < mine), c2 = c1 & (v2 < mine), c3 = c2 & (v3 < mine);
+        uint32_t skip = (uint32_t)c0 + (uint32_t)c1 + (uint32_t)c2 + (uint32_t)c3;
+        skip = (work & inBlk) ? (skip < budget ? skip : budget) : 0u;
+        pos = (pos + skip) & mask32; budget -= skip;
+        const bool drop1 = work & (budget == 0);
+        const bool recheck = work & !drop1 & (skip == 4);                  // may have left the block: next round
+        const bool doAtomic = work & !drop1 & !recheck;
+        unsigned long long old = kEmpty;
+        if (doAtomic)
+            old = atomicMin(reinterpret_cast<unsigned long long*>(&win[pos & (kWinSlots - 1)]), (unsigned long long)mine);
+        const bool fail = doAtomic & (old != kEmpty) & (old != mine);
+        const bool disp = fail & (old > mine);                             // displaced a later tuple: carry it on
+        mlo = disp ? (uint32_t)old : mlo; mhi = disp ? (uint32_t)(old >> 32) : mhi;
+        pos = fail ? ((pos + 1) & mask32) : pos;
+        const bool again = recheck | fail;
+        const bool dropped = drop0 | drop1;
+        drops += dropped ? 1u : 0u; dropSum += dropped ? key : 0u;
         // deferred tuples leave for the global queue (one returning atomic per round that has any)
         const unsigned long long dm = __ballot(toDefer);
         if (dm) {
@@ -215,20 +213,14 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
         uint32_t myMin = 0xFFFFFFFFu;
 #pragma unroll
         for (int j = 0; j < kPerThread; ++j) {
-            const bool in = full || (tb + tOff + 64 * j < clen);
-            bool ok = in;
-            if (PACKED) {
-                if (in) inSum += klo[j];
-                if (in && klo[j] == 0) { bad += 1; ok = false; }
-            } else {
-                if (in) inSum += pack64(khi[j], klo[j]);
-                if (in && (khi[j] != 0 || klo[j] == 0)) { bad += 1; ok = false; }
-            }
-            if (ok) {
-                liveMask |= 1u << j;
-                const uint32_t hb = ((klo[j] >> homeShift) & mask32) >> kBlkShift;
-                myMin = hb < myMin ? hb : myMin;
-            }
+            const bool in = full | (tb + tOff + 64 * j < clen);
+            const bool okKey = PACKED ? (klo[j] != 0) : ((khi[j] == 0) & (klo[j] != 0));
+            const bool ok = in & okKey;
+            inSum += in ? (PACKED ? (unsigned long long)klo[j] : (unsigned long long)pack64(khi[j], klo[j])) : 0ull;
+            bad += (in & !okKey) ? 1u : 0u;
+            liveMask |= ok ? (1u << j) : 0u;
+            const uint32_t hb = ((klo[j] >> homeShift) & mask32) >> kBlkShift;
+            myMin = (ok & (hb < myMin)) ? hb : myMin;
         }
         myMin = wave_min_u32(myMin);
         if (lane == 0 && myMin != 0xFFFFFFFFu) atomicMin(&sTileMin, myMin);
@@ -278,11 +270,9 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
                 const uint32_t home = (klo[j] >> homeShift) & mask32;
                 const uint32_t hb = home >> kBlkShift;
                 const bool lv = (liveMask >> j) & 1u;
-                uint32_t r0 = (lv && hb - wb < kWinBlocks) ? (hb & (kWinBlocks - 1)) : 0xFFu;
-                if (lv && (home & (kBlkSlots - 1)) > kBlkSlots - probeLen) {
-                    const uint32_t eb = ((home + probeLen - 1) & mask32) >> kBlkShift;
-                    if (eb - wb < kWinBlocks) need[eb & (kWinBlocks - 1)] = 0x10000u;   // straddle: always wanted
-                }
+                uint32_t r0 = (lv & (hb - wb < kWinBlocks)) ? (hb & (kWinBlocks - 1)) : 0xFFu;
+                const uint32_t eb = ((home + probeLen - 1) & mask32) >> kBlkShift;
+                if (lv & (eb != hb) & (eb - wb < kWinBlocks)) need[eb & (kWinBlocks - 1)] = 0x10000u;   // straddle: always wanted
                 if (seamTile) {
                     // wave-aggregated counting: near-sorted input puts a wavefront in 1-2 blocks
                     for (;;) {
@@ -293,11 +283,8 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
                         if (lane == (uint32_t)(__ffsll((long long)same) - 1)) atomicAdd(&need[lead], (unsigned int)__popcll(same));
                         if (r0 == lead) r0 = 0xFFu;
                     }
-                } else {
-                    // common case: the whole wavefront step sits in one block -> one LDS store
-                    const uint32_t lead = __builtin_amdgcn_readfirstlane(r0);
-                    if (__ballot(r0 != lead) == 0ull) { if (lane == 0 && lead != 0xFFu) need[lead] = 0x10000u; }
-                    else if (r0 != 0xFFu) need[r0] = 0x10000u;
+                } else if (r0 != 0xFFu) {
+                    need[r0] = 0x10000u;
                 }
             }
         }
@@ -332,18 +319,16 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
             uint32_t mhi = PACKED ? khi[j] : (idx0 + tb + tOff + 64 * j);
             uint32_t pos = (klo[j] >> homeShift) & mask32;
             const uint32_t blk = pos >> kBlkShift;
-            const bool own = lv && (blk - wb < kWinBlocks) && ((ownedMask >> (blk & (kWinBlocks - 1))) & 1u);
-            bool again = lv && !own;                                    // not owned: the retry round defers it
-            if (own) {
-                const uint64_t mine = pack64(mhi, mlo);
-                const unsigned long long old =
-                    atomicMin(reinterpret_cast<unsigned long long*>(&win[pos & (kWinSlots - 1)]), (unsigned long long)mine);
-                if (old != kEmpty) {
-                    if (old > mine) { mlo = (uint32_t)old; mhi = (uint32_t)(old >> 32); }   // displaced a later tuple
-                    pos = (pos + 1) & mask32;
-                    again = true;
-                }
-            }
+            const bool own = lv & (blk - wb < kWinBlocks) & (((ownedMask >> (blk & (kWinBlocks - 1))) & 1u) != 0);
+            const uint64_t mine = pack64(mhi, mlo);
+            unsigned long long old = kEmpty;
+            if (own)
+                old = atomicMin(reinterpret_cast<unsigned long long*>(&win[pos & (kWinSlots - 1)]), (unsigned long long)mine);
+            const bool fail = own & (old != kEmpty);                    // slot was taken
+            const bool disp = fail & (old > mine);                      // ... by a later tuple: it moves on instead
+            mlo = disp ? (uint32_t)old : mlo; mhi = disp ? (uint32_t)(old >> 32) : mhi;
+            pos = fail ? ((pos + 1) & mask32) : pos;
+            const bool again = fail | (lv & !own);                      // not owned: the retry round defers it
             const unsigned long long am = __ballot(again);
             if (am) {
                 if (again) {
