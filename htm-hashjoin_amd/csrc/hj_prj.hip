@@ -306,42 +306,139 @@ __device__ __forceinline__ uint32_t join_hash(uint32_t k)
 }
 static_assert(kJoinSlots == (1u << 15), "join_hash assumes 2^15 slots");
 
+constexpr int kJoinPre = 16;   // tuples per thread and relation prefetched in registers (16 x 1024 = 16384)
+
+// One persistent workgroup per CU walks the partitions pid = blockIdx.x, += gridDim.x. The LDS table takes
+// 128 KiB, so only one workgroup fits a CU and nothing else could hide the HBM latency of a partition's
+// 2 x 128 KiB: while partition p is built and probed out of registers, the first 16384 R and S tuples of
+// the next partition are already in flight into the other register set (explicit vmcnt wait at the top,
+// one unconditional clamped load path -- see hj_build_own.hip for why). Measured at 2^30: 13.4 ms -> see
+// profiles/.
 __global__ void __launch_bounds__(kJoinThreads)
 k_prj_join(const uint64_t* __restrict__ partR, const uint32_t* __restrict__ offR,
            const uint64_t* __restrict__ partS, const uint32_t* __restrict__ offS,
-           uint32_t radixBits, Counters* __restrict__ ctr)
+           uint32_t radixBits, uint32_t nParts, uint32_t nRtotal, uint32_t nStotal, Counters* __restrict__ ctr)
 {
     extern __shared__ uint32_t tab[];  // kJoinSlots
-    const uint32_t pid = blockIdx.x;
-    const uint32_t rb = offR[pid], re = offR[pid + 1];
-    const uint32_t nR = re - rb;
-    if (nR == 0) return;  // serial_radix_partition :531 queues only non-empty R parts
-    const uint32_t sb = partS ? offS[pid] : 0, se = partS ? offS[pid + 1] : 0;
-    const uint32_t idxMask = next_pow2_u32(nR) - 1;  // bucket idx mask, :242-245
     unsigned long long matches = 0, checksum = 0;
+    uint32_t overflowParts = 0;
+    const bool haveS = partS != nullptr;
 
-    for (uint32_t blk = rb; blk < re; blk += kJoinBlockTuples) {
-        const uint32_t bend = (re - blk > kJoinBlockTuples) ? blk + kJoinBlockTuples : re;
-        for (uint32_t i = threadIdx.x; i < kJoinSlots; i += kJoinThreads) tab[i] = kEmpty32;
-        __syncthreads();
-        for (uint32_t i = blk + threadIdx.x; i < bend; i += kJoinThreads) {
-            const uint32_t k = (uint32_t)partR[i] >> radixBits;  // distinguishes keys inside a partition
-            checksum += k & idxMask;                              // :249,256
-            uint32_t h = join_hash(k);
-            while (atomicCAS(&tab[h], kEmpty32, k) != kEmpty32) h = (h + 1) & (kJoinSlots - 1);
+    // Register pipeline: S(p) is loaded while R(p) is built, R(p+1) while S(p) is probed; each buffer is
+    // refilled only after its last use, so no copy of in-flight registers is ever needed.
+    uint64_t bufR[kJoinPre], bufS[kJoinPre];
+    auto load_R = [&](uint32_t pid) {   // clamped: every lane always loads a valid address; validity decided at use
+        const uint32_t rb0 = offR[pid < nParts ? pid : nParts - 1];
+#pragma unroll
+        for (int j = 0; j < kJoinPre; ++j) {
+            const uint32_t o = rb0 + j * kJoinThreads + threadIdx.x;
+            bufR[j] = partR[o < nRtotal ? o : nRtotal - 1];
         }
-        __syncthreads();
-        for (uint32_t i = sb + threadIdx.x; i < se; i += kJoinThreads) {
-            const uint32_t k = (uint32_t)partS[i] >> radixBits;
-            uint32_t h = join_hash(k);
-            for (;;) {
-                const uint32_t v = tab[h];
-                if (v == kEmpty32) break;
-                matches += (v == k);                              // :268-271
-                h = (h + 1) & (kJoinSlots - 1);
+    };
+    auto load_S = [&](uint32_t pid) {
+        const uint32_t sb0 = offS[pid];
+#pragma unroll
+        for (int j = 0; j < kJoinPre; ++j) {
+            const uint32_t o = sb0 + j * kJoinThreads + threadIdx.x;
+            bufS[j] = partS[o < nStotal ? o : nStotal - 1];
+        }
+    };
+    load_R(blockIdx.x);
+
+    for (uint32_t pid = blockIdx.x; pid < nParts; pid += gridDim.x) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // R(pid) has landed
+        __builtin_amdgcn_sched_barrier(0);
+        if (haveS) load_S(pid);                                // in flight while R is built
+        __builtin_amdgcn_sched_barrier(0);
+
+        const uint32_t rb = offR[pid], re = offR[pid + 1];
+        const uint32_t nR = re - rb;
+        if (nR == 0) {          // serial_radix_partition :531 queues only non-empty R parts (wave-uniform)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            load_R(pid + gridDim.x);
+            continue;
+        }
+        const uint32_t sb = haveS ? offS[pid] : 0, se = haveS ? offS[pid + 1] : 0;
+        const uint32_t nS = se - sb;
+        const uint32_t idxMask = next_pow2_u32(nR) - 1;  // bucket idx mask, :242-245
+
+        if (nR <= kJoinBlockTuples) {
+            // ---- the common case: the whole R partition fits one LDS table ----
+            for (uint32_t i = threadIdx.x; i < kJoinSlots; i += kJoinThreads) tab[i] = kEmpty32;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < kJoinPre; ++j) {
+                if (j * kJoinThreads + threadIdx.x < nR) {
+                    const uint32_t k = (uint32_t)bufR[j] >> radixBits;   // distinguishes keys inside a partition
+                    checksum += k & idxMask;                          // :249,256
+                    uint32_t h = join_hash(k);
+                    while (atomicCAS(&tab[h], kEmpty32, k) != kEmpty32) h = (h + 1) & (kJoinSlots - 1);
+                }
+            }
+            for (uint32_t i = rb + kJoinPre * kJoinThreads + threadIdx.x; i < re; i += kJoinThreads) {   // tuples 16384..
+                const uint32_t k = (uint32_t)partR[i] >> radixBits;
+                checksum += k & idxMask;
+                uint32_t h = join_hash(k);
+                while (atomicCAS(&tab[h], kEmpty32, k) != kEmpty32) h = (h + 1) & (kJoinSlots - 1);
+            }
+            __syncthreads();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // S(pid) has landed; bufR is free
+            __builtin_amdgcn_sched_barrier(0);
+            load_R(pid + gridDim.x);                           // in flight while S is probed
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < kJoinPre; ++j) {
+                if (j * kJoinThreads + threadIdx.x < nS) {
+                    const uint32_t k = (uint32_t)bufS[j] >> radixBits;
+                    uint32_t h = join_hash(k);
+                    for (;;) {
+                        const uint32_t v = tab[h];
+                        if (v == kEmpty32) break;
+                        matches += (v == k);                          // :268-271
+                        h = (h + 1) & (kJoinSlots - 1);
+                    }
+                }
+            }
+            for (uint32_t i = sb + kJoinPre * kJoinThreads + threadIdx.x; i < se; i += kJoinThreads) {
+                const uint32_t k = (uint32_t)partS[i] >> radixBits;
+                uint32_t h = join_hash(k);
+                for (;;) {
+                    const uint32_t v = tab[h];
+                    if (v == kEmpty32) break;
+                    matches += (v == k);
+                    h = (h + 1) & (kJoinSlots - 1);
+                }
+            }
+            __syncthreads();
+        } else {
+            // ---- oversized R partition (skew): several LDS builds, S probed against each ----
+            overflowParts += 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            load_R(pid + gridDim.x);
+            for (uint32_t blk = rb; blk < re; blk += kJoinBlockTuples) {
+                const uint32_t bend = (re - blk > kJoinBlockTuples) ? blk + kJoinBlockTuples : re;
+                for (uint32_t i = threadIdx.x; i < kJoinSlots; i += kJoinThreads) tab[i] = kEmpty32;
+                __syncthreads();
+                for (uint32_t i = blk + threadIdx.x; i < bend; i += kJoinThreads) {
+                    const uint32_t k = (uint32_t)partR[i] >> radixBits;
+                    checksum += k & idxMask;
+                    uint32_t h = join_hash(k);
+                    while (atomicCAS(&tab[h], kEmpty32, k) != kEmpty32) h = (h + 1) & (kJoinSlots - 1);
+                }
+                __syncthreads();
+                for (uint32_t i = sb + threadIdx.x; i < se; i += kJoinThreads) {
+                    const uint32_t k = (uint32_t)partS[i] >> radixBits;
+                    uint32_t h = join_hash(k);
+                    for (;;) {
+                        const uint32_t v = tab[h];
+                        if (v == kEmpty32) break;
+                        matches += (v == k);
+                        h = (h + 1) & (kJoinSlots - 1);
+                    }
+                }
+                __syncthreads();
             }
         }
-        __syncthreads();
     }
     // one atomic per wavefront
     for (int off = 32; off > 0; off >>= 1) {
@@ -352,7 +449,7 @@ k_prj_join(const uint64_t* __restrict__ partR, const uint32_t* __restrict__ offR
         if (matches) atomicAdd(&ctr->prjMatches, matches);
         if (checksum) atomicAdd(&ctr->prjChecksum, checksum);
     }
-    if (threadIdx.x == 0 && nR > kJoinBlockTuples) atomicAdd(&ctr->prjOverflowParts, 1ull);
+    if (threadIdx.x == 0 && overflowParts) atomicAdd(&ctr->prjOverflowParts, (unsigned long long)overflowParts);
 }
 
 // ---------------------------------------------------------------------------
@@ -479,8 +576,16 @@ void launch_prj(const PrjPlan& pl, const PrjBuffers& buf, const uint64_t* R, uin
                             hipFuncAttributeMaxDynamicSharedMemorySize, kJoinSlots * sizeof(uint32_t));
         attrSet = true;
     }
-    hipLaunchKernelGGL(k_prj_join, dim3(P), dim3(kJoinThreads), kJoinSlots * sizeof(uint32_t), s,
-                       buf.partR, w.offR, S ? buf.partS : nullptr, w.offS, pl.radixBits, ctr);
+    static int nCU = 0;
+    if (!nCU) {
+        int dev = 0;
+        nCU = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&nCU, hipDeviceAttributeMultiprocessorCount, dev);
+    }
+    const unsigned grid = P < (uint32_t)nCU ? P : (unsigned)nCU;   // one persistent workgroup per CU
+    hipLaunchKernelGGL(k_prj_join, dim3(grid), dim3(kJoinThreads), kJoinSlots * sizeof(uint32_t), s,
+                       buf.partR, w.offR, S ? buf.partS : nullptr, w.offS, pl.radixBits, P, (uint32_t)nR,
+                       (uint32_t)(S ? nS : 1), ctr);
 }
 
 // ---------------------------------------------------------------------------

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""The reference's shuffle-window sweep (experiments/probe.sh, motivation.sh: local_shuffle, rSize = 2^27,
+W = 2^0 .. 2^27) on the MI355X engine: open-addressing build+probe (auto variant) and PRJ per W, one JSON line
+each, in the reference's field order plus the device timings. Optional CPU leg (the oracle's threaded port)
+every 4th W. Usage: python tools/sweep.py [--log2n 27] [--reps 3] [--cpu] > profiles/rNN_sweep.jsonl"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import htm_hashjoin_amd as hj
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log2n", type=int, default=27)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--cpu", action="store_true")
+    ap.add_argument("--prj", action="store_true")
+    a = ap.parse_args()
+    n = 1 << a.log2n
+    S = hj.generate_data("sorted", n)
+    with hj.HashJoinContext(0) as ctx, hj.HashJoinContext(0) as pctx:
+        dS = ctx.dev_alloc(n * 8)
+        dR = ctx.dev_alloc(n * 8)
+        ctx.copy_h2d(dS, S)
+        ctx.reserve("atomic", n, n)
+        if a.prj:
+            pctx.reserve("prj", n, n)
+        for e in range(0, a.log2n + 1):
+            W = 1 << e
+            R = hj.generate_data("local_shuffle", n, n, W)
+            ctx.copy_h2d(dR, R)
+            best = None
+            for _ in range(a.reps):
+                ctx.build(dR, n)
+                ctx.probe(dS, n)
+                ctx.checksums()
+                r = ctx.fetch()
+                if best is None or r["total_us"] < best["total_us"]:
+                    best = r
+            line = {"algo": "atomic", "rSize": n, "probeLength": 4,
+                    "hashBuildTimeInMicroseconds": int(best["total_us"] + best["clear_us"]), "conflicts": best["conflicts"],
+                    "totalMatches": best["totalMatches"], "inputSum": best["inputSum"], "outputSum": best["outputSum"],
+                    "dataDistr": "local_shuffle", "shuffleRange": W, "device": "hip", "buildVariant": best["buildVariant"],
+                    "buildDeferred": best["buildDeferred"], "clear_us": best["clear_us"], "build_us": best["build_us"],
+                    "probe_us": best["probe_us"], "mtuples_per_s": 2 * n / (best["total_us"] + best["clear_us"])}
+            print(json.dumps(line), flush=True)
+            if a.prj:
+                pb = None
+                for _ in range(a.reps):
+                    pctx.prj_join(dR, n, dS, n)
+                    r = pctx.fetch()
+                    if pb is None or r["total_us"] < pb["total_us"]:
+                        pb = r
+                print(json.dumps({"algo": "prj", "rSize": n, "hashBuildTimeInMicroseconds": int(pb["total_us"]),
+                                  "totalMatches": pb["totalMatches"], "results": pb["prjChecksum"], "radixBits": pb["radixBits"],
+                                  "dataDistr": "local_shuffle", "shuffleRange": W, "device": "hip",
+                                  "partition_us": pb["partition_us"], "join_us": pb["join_us"],
+                                  "mtuples_per_s": 2 * n / pb["total_us"]}), flush=True)
+            if a.cpu and e % 4 == 2:
+                from oracle import oracle   # baseline leg only
+                threads = min(64, os.cpu_count() or 1)
+                c = oracle.build_probe_mt(R, S, 4, 64, threads, atomic=True)
+                print(json.dumps({"algo": "atomic", "rSize": n, "probeLength": 4,
+                                  "hashBuildTimeInMicroseconds": int(c["build_us"] + c["probe_us"]), "conflicts": c["conflicts"],
+                                  "totalMatches": c["totalMatches"], "inputSum": c["inputSum"], "outputSum": c["outputSumAtomic"],
+                                  "dataDistr": "local_shuffle", "shuffleRange": W, "device": "cpu", "cpu_threads": threads,
+                                  "mtuples_per_s": 2 * n / (c["build_us"] + c["probe_us"])}), flush=True)
+        ctx.dev_free(dR)
+        ctx.dev_free(dS)
+
+
+if __name__ == "__main__":
+    main()
