@@ -302,3 +302,46 @@ def test_sharded_kernels_on_one_gpu(ctx, G, dist, window, variant):
                 tot[k] += res[k]
             c.dev_free(d_r); c.dev_free(d_s)
     assert tot == want
+
+
+def test_skew_probe_side_zipf(ctx):
+    """BASELINE config 5 at reduced size: R unique (shuffle), |S| = 8|R| + 3 drawn Zipf(0.9) over R's key
+    domain (mc/src/genzipf.c method). Every S tuple finds exactly its one R tuple: totalMatches = |S|,
+    on the open-addressing path (both build variants) and on PRJ."""
+    n = 1 << 18
+    R = oracle.generate_data("shuffle", n)
+    S = hj.generate_data("zipf", 8 * n + 3, n, 16, zipf_theta=0.9)
+    assert np.array_equal(S, oracle.generate_zipf(8 * n + 3, n, 0.9, 0))
+    want = oracle.build_probe_seq(R, S, 4)
+    assert want["conflicts"] == 0 and want["totalMatches"] == S.size
+    for variant in (1, 2):
+        got = ctx.run("atomic", R, S, buildVariant=variant)
+        check_oa(got, want)
+    got = ctx.run("prj", R, S)
+    assert got["totalMatches"] == S.size
+
+
+def test_main_cli_on_gpu():
+    """The reference's command line end to end on the GPU: `main --algo atomic|htm|prj` prints the reference's
+    JSON fields (NoCCHashBuild.hpp:127-146 order) with the pinned sequential-order values."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    main = os.path.join(root, "htm-hashjoin_amd", "bin", "main")
+
+    def run(*args):
+        r = subprocess.run([main, *map(str, args)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        return json.loads(r.stdout)
+
+    j = run("--algo", "atomic", "--rSize", 1048576, "--probeLength", 4, "--dataDistr", "uniform")
+    assert list(j)[:8] == ["algo", "rSize", "probeLength", "hashBuildTimeInMicroseconds", "conflicts", "totalMatches",
+                           "inputSum", "outputSum"]
+    assert (j["conflicts"], j["totalMatches"], j["inputSum"]) == (176864, 871712, 549507039110)
+    assert j["outputSum"] == j["inputSum"] and j["device"] == "hip"     # table sum + dropped keys = input sum
+    j = run("--algo", "htm", "--transactionSize", 16, "--rSize", 1048576, "--dataDistr", "local_shuffle", "--shuffleRange", 1024)
+    assert (j["algo"], j["transactionSize"], j["conflicts"], j["totalMatches"], j["inputSum"], j["outputSum"]) == (
+        "htm", 16, 0, 1048576, 549756338176, 549756338176)
+    j = run("--algo", "atomic", "--rSize", 65536, "--dataDistr", "sorted", "--probe", 0)                 # ENABLE_PROBE 0
+    assert "totalMatches" not in j and j["conflicts"] == 0
+    j = run("--algo", "prj", "--rSize", 1048576, "--dataDistr", "shuffle", "--radixBits", 14)
+    assert j["totalMatches"] == 1048576 and j["results"] == 33030144                                      # mc PRO "Results"
