@@ -232,16 +232,39 @@ k_radix_scatter(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, Pas
 
     const ulonglong2* in2 = reinterpret_cast<const ulonglong2*>(in);
     const uint32_t b0 = r.begin & ~1u;
+    // Register prefetch of the next tile (one unconditional, clamped load path; waits placed by hand: see
+    // hj_build_own.hip). vmcnt counts loads and stores together in issue order: after a full tile every
+    // thread has exactly 2*kTileVec stores younger than the prefetch loads, so vmcnt(16) waits for the
+    // loads only and leaves the stores in flight.
+    static_assert(2 * kTileVec == 16, "vmcnt immediate below assumes 16 stores per thread per full tile");
+    const uint32_t lastVec = (r.end - 1) >> 1;
+    ulonglong2 nxt[kTileVec];
+    auto issue = [&](uint64_t tb) {
+#pragma unroll
+        for (int k = 0; k < kTileVec; ++k) {
+            const uint64_t v = (tb >> 1) + (uint64_t)k * kBlock + threadIdx.x;
+            nxt[k] = in2[v < lastVec ? v : lastVec];
+        }
+    };
+    issue(b0);
+    bool prevFull = false;
     for (uint64_t tb = b0; tb < r.end; tb += kTile) {
         if (threadIdx.x < kMaxFan) tileCnt[threadIdx.x] = 0;
+        if (prevFull) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ulonglong2 cur[kTileVec];
+#pragma unroll
+        for (int k = 0; k < kTileVec; ++k) cur[k] = nxt[k];
+        __builtin_amdgcn_sched_barrier(0);
+        issue(tb + kTile);
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         uint64_t tv[2 * kTileVec];
         uint32_t br[2 * kTileVec];  // bin << 16 | rank within (tile, bin); rank < 4096
 #pragma unroll
         for (int k = 0; k < kTileVec; ++k) {
             const uint64_t i = tb + 2 * ((uint64_t)k * kBlock + threadIdx.x);
-            ulonglong2 t = make_ulonglong2(0, 0);
-            if (i < r.end) t = in2[i >> 1];
+            ulonglong2 t = cur[k];
             if (p.packIdxBase != ~0ull) {   // shard scatter: the input index travels above the key
                 t.x = ((p.packIdxBase + i) << 32) | (uint32_t)t.x;
                 t.y = ((p.packIdxBase + i + 1) << 32) | (uint32_t)t.y;
@@ -281,6 +304,7 @@ k_radix_scatter(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, Pas
         }
         __syncthreads();
         if (threadIdx.x < p.fan) cursor[threadIdx.x] += tileCnt[threadIdx.x];
+        prevFull = (valid == (uint32_t)kTile);
         // (next iteration's first barrier orders the cursor update)
     }
 }
