@@ -66,6 +66,10 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 
 __device__ __forceinline__ uint64_t pack64(uint32_t hi, uint32_t lo) { return ((uint64_t)hi << 32) | lo; }
 
+#ifndef HJ_DRAIN_AT
+#define HJ_DRAIN_AT 64
+#endif
+constexpr uint32_t kDrainAt = HJ_DRAIN_AT;            // run retry rounds once this many entries wait (<= 64)
 constexpr int kQCap = 128;                        // per-wavefront retry queue entries (LDS)
 
 // owner[blk]: 0 = free, otherwise (workgroup id + 1).
@@ -313,7 +317,7 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
 #pragma unroll
         for (int j = 0; j < kPerThread; ++j) {
             if (ABL & 1) break;
-            while (qCount >= 64u) retry_round();                        // keep room for one full step
+            while (qCount >= kDrainAt) retry_round();                   // keep room for one full step
             const bool lv = (liveMask >> j) & 1u;
             uint32_t mlo = klo[j];
             uint32_t mhi = PACKED ? khi[j] : (idx0 + tb + tOff + 64 * j);

@@ -1,0 +1,10 @@
+mkdir -p gpurun_out; rm -f gpurun_out/drain.log
+for d in 1 24 48 64; do
+  cp tools/dbg/lib_drain_$d.so htm-hashjoin_amd/lib/libhtmjoin_hip.so
+  for cfg in "uniform 16" "local_shuffle 1024"; do
+    set -- $cfg
+    echo "drain=$d dist=$1" >> gpurun_out/drain.log
+    timeout -k 10 120 python bench.py --log2n 27 --steps 5 --warmup 1 --no-extra --no-cpu-baseline --build-variant 2 --dist $1 --shuffle-range $2 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(round(d['roofline']['launch_us']), d['result']['conflicts'], d['ms_per_step'])" >> gpurun_out/drain.log 2>&1 || exit 1
+  done
+done
+cat gpurun_out/drain.log
