@@ -9,8 +9,9 @@ piece of R and of S. Per join:
   2. counts      one all_to_all_single of the G per-destination counts (R and S together)
   3. scatter     tuples grouped by destination; an R tuple travels as (globalIndex << 32 | key) so
                  that index priority survives the exchange           -> hj_shard_scatter_dev
-  4. exchange    one all_to_all_single per relation; every rank sends 1/G of its tuples to every
-                 peer directly, so all xGMI links carry traffic at once
+  4. exchange    one all_to_all_single per relation (async: R's exchange overlaps the split of S, S's
+                 exchange overlaps the local build); every rank sends 1/G of its tuples to every peer
+                 directly, so all xGMI links carry traffic at once
   5. local join  open-addressing build of the received R into a table of 2*|R_local| slots by
                  global index priority, home slot = (key >> log2 G) & mask (the shard bits are the
                  same for every local tuple), probe with the received S
@@ -80,8 +81,10 @@ class HipShardEngine:
             self.ctx.reserve("atomic", r, max_s, buildVariant=self.build_variant)
             self._reserved = key
 
-    def build_probe(self, r_packed, home_shift, table_size, s_keys):
+    def build(self, r_packed, home_shift, table_size):
         self.ctx.build_packed(r_packed.data_ptr(), r_packed.numel(), home_shift, table_size)
+
+    def probe(self, s_keys):
         self.ctx.probe(s_keys.data_ptr(), s_keys.numel())
 
     def finish(self):
@@ -105,7 +108,7 @@ class ShardedJoin:
     def _exchange_counts(self, cnt_r, cnt_s):
         both = self.torch.cat([cnt_r, cnt_s]).reshape(2, self.world).t().contiguous()   # [dest][R,S]
         recv = self.torch.empty_like(both)
-        if self.world > 1:
+        if self.dist is not None:
             self.dist.all_to_all_single(recv.view(-1), both.view(-1))
         else:
             recv.copy_(both)
@@ -113,26 +116,36 @@ class ShardedJoin:
         got = recv.cpu().tolist()
         return [s[0] for s in send], [s[1] for s in send], [g[0] for g in got], [g[1] for g in got]
 
-    def _exchange(self, send, send_counts, recv_counts):
+    def _exchange_async(self, send, send_counts, recv_counts):
+        """Starts the all-to-all of one relation; returns (output tensor, work handle or None). With NCCL/RCCL the
+        collective runs on the backend's own stream behind the kernels already enqueued on the current stream,
+        and work.wait() only makes the current stream wait for it (no host block)."""
         out = self.e.empty(sum(recv_counts))
-        if self.world > 1:
-            self.dist.all_to_all_single(out, send, output_split_sizes=recv_counts, input_split_sizes=send_counts)
-        else:
-            out.copy_(send)
-        return out
+        if self.dist is not None:
+            work = self.dist.all_to_all_single(out, send, output_split_sizes=recv_counts, input_split_sizes=send_counts,
+                                               async_op=True)
+            return out, work
+        out.copy_(send)
+        return out, None
 
     def step(self, r_local, s_local, idx_base, table_size):
-        """One build+probe over this rank's shards. Everything is enqueued; call result() to sync."""
+        """One build+probe over this rank's shards. Everything is enqueued; call result() to sync.
+        The exchange of R overlaps the split of S, and the exchange of S overlaps the local build."""
         e = self.e
         cnt_r = e.histogram(r_local, self.world)
         cnt_s = e.histogram(s_local, self.world)
         send_r, send_s, recv_r, recv_s = self._exchange_counts(cnt_r, cnt_s)
         out_r = e.scatter(r_local, self.world, cnt_r, idx_base)     # (gidx << 32 | key)
+        got_r, work_r = self._exchange_async(out_r, send_r, recv_r)
         out_s = e.scatter(s_local, self.world, cnt_s, None)         # unchanged tuples
-        got_r = self._exchange(out_r, send_r, recv_r)
-        got_s = self._exchange(out_s, send_s, recv_s)
+        got_s, work_s = self._exchange_async(out_s, send_s, recv_s)
         e.reserve(table_size, got_r.numel(), got_s.numel())
-        e.build_probe(got_r, self.strip, table_size, got_s)
+        if work_r is not None:
+            work_r.wait()
+        e.build(got_r, self.strip, table_size)
+        if work_s is not None:
+            work_s.wait()
+        e.probe(got_s)
         self.last = {"sent_r": sum(send_r) - send_r[self.rank], "sent_s": sum(send_s) - send_s[self.rank],
                      "recv_r": got_r.numel(), "recv_s": got_s.numel()}
         self._keep = (out_r, out_s, got_r, got_s)   # alive until the stream has consumed them
@@ -141,7 +154,7 @@ class ShardedJoin:
         r = self.e.finish()
         keys = ("conflicts", "totalMatches", "inputSum", "tableSumFull", "conflictSum", "buildDeferred")
         t = self.torch.tensor([r[k] for k in keys], dtype=self.torch.int64)
-        if self.world > 1:
+        if self.dist is not None:
             t = t.to(self.e.dev) if hasattr(self.e, "dev") else t
             self.dist.all_reduce(t)
             t = t.cpu()

@@ -44,10 +44,13 @@ class OracleShardEngine:
     def reserve(self, table_size, max_r, max_s):
         pass
 
-    def build_probe(self, r_packed, home_shift, table_size, s_keys):
+    def build(self, r_packed, home_shift, table_size):
         p = r_packed.numpy().view(np.uint64)
         p = np.sort(p)                                  # global index is the high field: sort = global input order
-        keys = p & np.uint64(0xFFFFFFFF)
+        self._built = (p & np.uint64(0xFFFFFFFF), home_shift, table_size)
+
+    def probe(self, s_keys):
+        keys, home_shift, table_size = self._built
         s = s_keys.numpy().view(np.uint64)
         self._res = oracle.build_probe_seq_ts(keys, s, table_size, home_shift)
 
