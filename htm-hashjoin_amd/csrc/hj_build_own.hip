@@ -463,30 +463,40 @@ k_build_deferred(const DeferredEntry* __restrict__ queue, const unsigned long lo
 }
 
 // Locality probe (the reference samples a prefix to decide whether to switch to the
-// radix join, HTMHashBuild.hpp:100-154): over nSample tiles spread across R, count
-// the tiles whose home-slot span fits the LDS window.
+// radix join, HTMHashBuild.hpp:100-154): over nSample tiles spread across R, count the
+// tuples that would fall outside the LDS window k_build_own would place for their tile
+// (window base = the tile's lowest home block - kBackBlocks) and therefore be deferred.
+// out[0] = tuples outside, out[1] = tuples looked at.
 __global__ void __launch_bounds__(kBlock)
 k_sample_locality(const uint64_t* __restrict__ R, uint64_t n, uint64_t mask, uint32_t homeShift, uint32_t nSample,
-                  unsigned int* __restrict__ fitCount)
+                  unsigned int* __restrict__ out)
 {
-    __shared__ unsigned long long sMin, sMax;
+    __shared__ unsigned int sMinBlk, sOutside;
     const uint64_t tiles = (n + kOwnTile - 1) / kOwnTile;
     for (uint32_t s = blockIdx.x; s < nSample; s += gridDim.x) {
         const uint64_t tile = (tiles * s) / nSample;
         const uint64_t b = tile * kOwnTile, e = (b + kOwnTile < n) ? b + kOwnTile : n;
-        if (threadIdx.x == 0) { sMin = ~0ull; sMax = 0; }
+        if (threadIdx.x == 0) { sMinBlk = 0xFFFFFFFFu; sOutside = 0; }
         __syncthreads();
-        unsigned long long lo = ~0ull, hi = 0;
+        uint32_t lo = 0xFFFFFFFFu;
         for (uint64_t i = b + threadIdx.x; i < e; i += kBlock) {
-            const unsigned long long h = ((uint32_t)R[i] >> homeShift) & mask;
-            lo = h < lo ? h : lo; hi = h > hi ? h : hi;
+            const uint32_t hb = (uint32_t)((((uint32_t)R[i] >> homeShift) & mask) >> kBlkShift);
+            lo = hb < lo ? hb : lo;
         }
-        if (lo != ~0ull) { atomicMin(&sMin, lo); atomicMax(&sMax, hi); }
+        lo = wave_min_u32(lo);
+        if ((threadIdx.x & 63) == 0 && lo != 0xFFFFFFFFu) atomicMin(&sMinBlk, lo);
         __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned long long span = sMax >= sMin ? sMax - sMin : 0;
-            if (span + 4 <= (unsigned long long)(kWinSlots - kBackBlocks * kBlkSlots)) atomicAdd(fitCount, 1u);
+        const uint32_t wbase = sMinBlk > kBackBlocks ? sMinBlk - kBackBlocks : 0;
+        uint32_t outside = 0;
+        for (uint64_t i = b + threadIdx.x; i < e; i += kBlock) {      // second sweep hits L2
+            const uint32_t hb = (uint32_t)((((uint32_t)R[i] >> homeShift) & mask) >> kBlkShift);
+            outside += (hb - wbase >= kWinBlocks) ? 1u : 0u;
         }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) outside += __shfl_down(outside, off, 64);
+        if ((threadIdx.x & 63) == 0 && outside) atomicAdd(&sOutside, outside);
+        __syncthreads();
+        if (threadIdx.x == 0) { atomicAdd(&out[0], sOutside); atomicAdd(&out[1], (unsigned int)(e - b)); }
         __syncthreads();
     }
 }
@@ -499,7 +509,7 @@ bool own_supported(uint64_t tableSize) { return tableSize >= (uint64_t)kWinSlots
 void launch_sample_locality(const uint64_t* R, uint64_t n, uint64_t tableSize, uint32_t homeShift, uint32_t nSample,
                             unsigned int* fitCount, hipStream_t s)
 {
-    (void)hipMemsetAsync(fitCount, 0, sizeof(unsigned int), s);
+    (void)hipMemsetAsync(fitCount, 0, 2 * sizeof(unsigned int), s);
     hipLaunchKernelGGL(k_sample_locality, dim3(nSample < 256 ? nSample : 256), dim3(kBlock), 0, s,
                        R, n, tableSize - 1, homeShift, nSample, fitCount);
 }
