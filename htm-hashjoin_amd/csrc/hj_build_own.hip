@@ -66,6 +66,9 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 
 __device__ __forceinline__ uint64_t pack64(uint32_t hi, uint32_t lo) { return ((uint64_t)hi << 32) | lo; }
 
+#ifndef HJ_LOOK_FIRST
+#define HJ_LOOK_FIRST 1
+#endif
 #ifndef HJ_DRAIN_AT
 #define HJ_DRAIN_AT 64
 #endif
@@ -146,7 +149,7 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
         // look before leaping: read the next 4 slots when they sit in this (owned) block -- otherwise
         // read the block's first 4 slots and ignore them. Slot values only decrease, so a slot seen
         // below `mine` stays below it.
-        const bool inBlk = (pos & (kBlkSlots - 1)) <= kBlkSlots - 4;
+        const bool inBlk = HJ_LOOK_FIRST && ((pos & (kBlkSlots - 1)) <= kBlkSlots - 4);
         const uint32_t rd = work ? (inBlk ? pos : (pos & ~(kBlkSlots - 1))) : 0u;
         const uint64_t* w = &win[rd & (kWinSlots - 1)];
         const uint64_t v0 = w[0], v1 = w[1], v2 = w[2], v3 = w[3];
