@@ -7,9 +7,9 @@ One "step" = one pass of the hot path over one batch: clear table -> build(R) ->
 with R and S already resident in HBM (DataGen inputs, generated on the host and copied
 in before the timed region). N=1 workload: |R| = |S| = 2^30 uint32-key tuples, `uniform`
 (BASELINE.json metric; configs[1]'s operator at the metric's size). For N > 1 (launched
-with torch.distributed.run, one rank per GPU) the SAME total workload is split over the
-ranks ("strong" scaling: rank g holds the g-th 1/N piece of R and of S); tuples are
-exchanged by key radix with one all-to-all per relation over RCCL and joined locally
+with torch.distributed.run, one rank per GPU) every rank holds its own 2^log2n tuples of
+R and of S ("weak" scaling; --strong splits the N=1 total instead); tuples are exchanged
+by key radix with one all-to-all per relation over RCCL and joined locally
 (htm_hashjoin_amd/sharded.py).
 
 Rank 0 prints ONE JSON line. `value` = (|R|+|S|) summed over all ranks / max-over-ranks
@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the other_workloads legs")
     ap.add_argument("--cpu-sample-log2n", type=int, default=27)
     ap.add_argument("--build-variant", type=int, default=0, help="0 auto, 1 global atomics, 2 LDS window")
+    ap.add_argument("--strong", action="store_true", help="N>1: split the N=1 total instead of 2^log2n per GPU")
     return ap.parse_args()
 
 

@@ -27,7 +27,7 @@ struct hj_ctx {
     uint64_t* table = nullptr;
     uint64_t tableCapSlots = 0;   // allocated slots incl. slack
     uint64_t tableSize = 0;       // live table (2*rSize) of the last build
-    uint32_t homeShift = 0;       // home slot = (key >> homeShift) & (tableSize-1)
+    uint32_t strip = 0, shardId = 0; // slot format of the current table (hj_device.h); 0,0 unless radix-sharded
     uint64_t rSize = 0, sSize = 0;
     bool built = false;
     // ownership build (variant 2)
@@ -259,11 +259,11 @@ int hj_reserve(hj_ctx* c, const hj_params* params, uint64_t rSize, uint64_t sSiz
 }
 
 // Shared by hj_build_dev (DataGen tuples) and hj_build_packed_dev (index-packed tuples).
-static int build_common(hj_ctx* c, const uint64_t* d, uint64_t n, bool packed, uint32_t homeShift,
+static int build_common(hj_ctx* c, const uint64_t* d, uint64_t n, bool packed, uint32_t strip, uint32_t shard,
                         uint64_t tableSize, uint64_t idxBase)
 {
     HJ_HIP(c, hipSetDevice(c->device));
-    c->rSize = n; c->sSize = 0; c->tableSize = tableSize; c->homeShift = homeShift;
+    c->rSize = n; c->sSize = 0; c->tableSize = tableSize; c->strip = strip; c->shardId = shard;
     for (bool& b : c->evSet) b = false;
     c->prjRan = false;
     HJ_HIP(c, hipMemsetAsync(c->dCtr, 0, sizeof(Counters), c->stream));
@@ -281,7 +281,7 @@ static int build_common(hj_ctx* c, const uint64_t* d, uint64_t n, bool packed, u
             // most 1/12 of the tuples (measured at 2^27, local_shuffle: W=2^11 defers 3.8 % and runs 2.1 ms
             // against 5.7 ms for the global-atomic kernel; W=2^12 defers 36 % and runs 12.9 ms against 5.8)
             const uint32_t nSample = 256;
-            launch_sample_locality(d, n, tableSize, homeShift, nSample, c->fitCount, c->stream);
+            launch_sample_locality(d, n, tableSize, strip, nSample, c->fitCount, c->stream);
             HJ_HIP(c, hipMemcpyAsync(c->hFit, c->fitCount, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
             HJ_HIP(c, hipStreamSynchronize(c->stream));
             if ((uint64_t)c->hFit[0] * 12 <= (uint64_t)c->hFit[1]) variant = 2;
@@ -290,14 +290,14 @@ static int build_common(hj_ctx* c, const uint64_t* d, uint64_t n, bool packed, u
     c->variantUsed = variant;
     if (variant == 2) {
         if ((rc = record(c, EV_BUILD0))) return rc;
-        launch_build_own(d, n, packed, homeShift, c->table, tableSize, probe_len(c->params), idxBase, c->ownerBuf,
+        launch_build_own(d, n, packed, strip, shard, c->table, tableSize, probe_len(c->params), idxBase, c->ownerBuf,
                          c->queueBuf, c->queueCount, c->dCtr, c->ev[EV_BUILD_A], c->stream);
         c->evSet[EV_BUILD_A] = true;
     } else {
         launch_fill_empty(c->table, tableSize + kTableSlack, c->stream);
         launch_set_full_range(tableSize, c->dCtr, c->stream);
         if ((rc = record(c, EV_BUILD0))) return rc;
-        if (packed) { if (n) launch_build_packed(d, n, c->table, tableSize, homeShift, probe_len(c->params), c->dCtr, c->stream); }
+        if (packed) { if (n) launch_build_packed(d, n, c->table, tableSize, strip, shard, probe_len(c->params), c->dCtr, c->stream); }
         else launch_build_atomic_min(d, n, c->table, tableSize, probe_len(c->params), idxBase, c->dCtr, c->stream);
     }
     if ((rc = record(c, EV_BUILD1))) return rc;
@@ -313,17 +313,19 @@ int hj_build_dev(hj_ctx* c, const uint64_t* dR, uint64_t rSize, uint64_t idxBase
     if (!is_pow2(rSize) || 2 * rSize + kTableSlack > c->tableCapSlots)
         return fail(c, HJ_ERR_STATE, "hj_build_dev: hj_reserve() not called for this rSize");
     if (idxBase + rSize > (1ull << 32)) return fail(c, HJ_ERR_INVALID, "hj_build_dev: index range exceeds 32 bits");
-    return build_common(c, dR, rSize, false, 0, 2 * rSize, idxBase);
+    return build_common(c, dR, rSize, false, 0, 0, 2 * rSize, idxBase);
 }
 
-int hj_build_packed_dev(hj_ctx* c, const uint64_t* dPacked, uint64_t n, uint32_t homeShift, uint64_t tableSize)
+int hj_build_packed_dev(hj_ctx* c, const uint64_t* dPacked, uint64_t n, uint32_t stripBits, uint32_t shardId,
+                        uint64_t tableSize)
 {
     if (!c || (!dPacked && n)) return HJ_ERR_INVALID;
     if (c->params.algo == HJ_ALGO_PRJ) return fail(c, HJ_ERR_STATE, "hj_build_packed_dev: context is reserved for PRJ");
-    if (homeShift > 16) return fail(c, HJ_ERR_INVALID, "hj_build_packed_dev: homeShift must be in [0,16]");
+    if (stripBits > 6 || shardId >= (1u << stripBits))
+        return fail(c, HJ_ERR_INVALID, "hj_build_packed_dev: stripBits must be in [0,6] and shardId < 2^stripBits");
     if (!is_pow2(tableSize) || tableSize + kTableSlack > c->tableCapSlots)
         return fail(c, HJ_ERR_STATE, "hj_build_packed_dev: hj_reserve() not called for this table size");
-    return build_common(c, dPacked, n, true, homeShift, tableSize, 0);
+    return build_common(c, dPacked, n, true, stripBits, shardId, tableSize, 0);
 }
 
 int hj_probe_dev(hj_ctx* c, const uint64_t* dS, uint64_t sSize)
@@ -333,7 +335,7 @@ int hj_probe_dev(hj_ctx* c, const uint64_t* dS, uint64_t sSize)
     HJ_HIP(c, hipSetDevice(c->device));
     int rc;
     if ((rc = record(c, EV_PROBE0))) return rc;
-    if (sSize) launch_probe(dS, sSize, c->table, c->tableSize, c->homeShift, probe_len(c->params), c->dCtr, c->stream);
+    if (sSize) launch_probe(dS, sSize, c->table, c->tableSize, c->strip, probe_len(c->params), c->dCtr, c->stream);
     if ((rc = record(c, EV_PROBE1))) return rc;
     HJ_HIP(c, hipGetLastError());
     c->sSize += sSize;
@@ -373,7 +375,7 @@ int hj_checksums_dev(hj_ctx* c)
     HJ_HIP(c, hipSetDevice(c->device));
     // zero the two sums so the call is idempotent
     HJ_HIP(c, hipMemsetAsync(&c->dCtr->tableSumHalf, 0, 2 * sizeof(unsigned long long), c->stream));
-    launch_table_sums(c->table, c->tableSize, c->tableSize / 2, c->dCtr, c->stream);
+    launch_table_sums(c->table, c->tableSize, c->tableSize / 2, c->strip, c->shardId, c->dCtr, c->stream);
     HJ_HIP(c, hipGetLastError());
     return HJ_OK;
 }
@@ -431,7 +433,7 @@ int hj_export_table(hj_ctx* c, uint64_t* host_table, uint64_t tableSize)
     HJ_HIP(c, hipMemcpy(&k, c->dCtr, sizeof(k), hipMemcpyDeviceToHost));
     const uint64_t lo = k.validLo, hi = k.validHiEx + 512 < tableSize ? k.validHiEx + 512 : tableSize;
     for (uint64_t i = 0; i < tableSize; ++i)
-        host_table[i] = (i < lo || i >= hi || host_table[i] == kEmpty) ? 0 : (uint32_t)host_table[i];
+        host_table[i] = (i < lo || i >= hi || host_table[i] == kEmpty) ? 0 : full_key(slot_key(host_table[i], c->strip), c->strip, c->shardId);
     return HJ_OK;
 }
 
@@ -492,18 +494,20 @@ int hj_shard_histogram_dev(hj_ctx* c, const uint64_t* dIn, uint64_t n, uint32_t 
 }
 
 int hj_shard_scatter_dev(hj_ctx* c, const uint64_t* dIn, uint64_t n, uint32_t nShards, uint32_t mode,
-                         uint64_t /*tableSize*/, const uint64_t* dCounts, uint64_t packIdxBase, uint64_t* dOut)
+                         uint64_t /*tableSize*/, const uint64_t* dCounts, uint64_t packIdxBase, uint32_t stripBits,
+                         uint64_t* dOut)
 {
     if (!c || (!dIn && n) || !dCounts || (!dOut && n)) return HJ_ERR_INVALID;
     int rc = shard_check(c, "hj_shard_scatter_dev: nShards must be a power of two <= 64", n, nShards, mode);
     if (rc) return rc;
-    if (packIdxBase != ~0ull && packIdxBase + n > (1ull << 32))
-        return fail(c, HJ_ERR_INVALID, "hj_shard_scatter_dev: index range exceeds 32 bits");
+    if (stripBits > 6) return fail(c, HJ_ERR_INVALID, "hj_shard_scatter_dev: stripBits must be in [0,6]");
+    if (packIdxBase != ~0ull && packIdxBase + n > (1ull << (32 + stripBits)))
+        return fail(c, HJ_ERR_INVALID, "hj_shard_scatter_dev: index range exceeds 32 + stripBits bits");
     hj_ctx::ShardPlan* slot = nullptr;
     for (auto& sp : c->shard) if (sp.in == dIn && sp.n == n && sp.nShards == nShards && sp.work) slot = &sp;
     if (!slot) return fail(c, HJ_ERR_STATE, "hj_shard_scatter_dev: call hj_shard_histogram_dev on this input first");
     HJ_HIP(c, hipSetDevice(c->device));
-    launch_shard_scatter_ordered(dIn, n, nShards, slot->work, packIdxBase, dOut, c->stream);
+    launch_shard_scatter_ordered(dIn, n, nShards, slot->work, packIdxBase, stripBits, dOut, c->stream);
     HJ_HIP(c, hipGetLastError());
     slot->in = nullptr;   // consumed
     return HJ_OK;

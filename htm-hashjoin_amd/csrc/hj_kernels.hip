@@ -71,20 +71,18 @@ void launch_fill_empty(uint64_t* table, uint64_t nSlots, hipStream_t s)
 // ---------------------------------------------------------------------------
 // build
 // ---------------------------------------------------------------------------
-// Inserts `mine` = (index << 32 | key) starting at slot `pos` with `budget` probes
-// left. The home slot of a key is (key >> homeShift) & homeMask: homeShift is 0
-// except for radix-sharded input, where the low log2(shards) key bits are the same
-// for every tuple of a shard and are left out of the slot number; homeMask =
-// tableSize - 1.
+// Inserts `mine` = (index << (32 - strip) | key') starting at slot `pos` with `budget`
+// probes left (slot format: hj_device.h). The home slot of a tuple is key' & homeMask,
+// homeMask = tableSize - 1; `shard` only serves to report dropped keys in full.
 __device__ __forceinline__ void insert_priority(uint64_t* __restrict__ table, uint64_t homeMask,
-                                                uint32_t homeShift, uint32_t probeLen,
+                                                uint32_t strip, uint32_t shard, uint32_t probeLen,
                                                 uint64_t mine, uint64_t pos, uint32_t budget,
                                                 unsigned long long& drops, unsigned long long& dropSum)
 {
     for (;;) {
         if (budget == 0) {  // NoCCHashBuild.hpp:57-58
             drops += 1;
-            dropSum += (uint32_t)mine;
+            dropSum += full_key(slot_key(mine, strip), strip, shard);
             return;
         }
         const unsigned long long old =
@@ -94,7 +92,7 @@ __device__ __forceinline__ void insert_priority(uint64_t* __restrict__ table, ui
             // displaced a later tuple: carry it on from the next slot with the
             // budget it has left there
             mine = old;
-            const uint64_t home = ((uint32_t)old >> homeShift) & homeMask;
+            const uint64_t home = slot_key(old, strip) & homeMask;
             const uint32_t disp = (uint32_t)((pos - home) & homeMask);
             budget = probeLen - (disp + 1);
         } else {
@@ -112,7 +110,7 @@ __device__ __forceinline__ void build_one(uint64_t t, uint64_t idx, uint64_t* __
     inSum += t;
     if ((t >> 32) != 0 || t == 0) { bad += 1; return; }
     const uint64_t mine = (idx << 32) | t;
-    insert_priority(table, mask, 0, probeLen, mine, t & mask, probeLen, drops, dropSum);
+    insert_priority(table, mask, 0, 0, probeLen, mine, t & mask, probeLen, drops, dropSum);
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -148,19 +146,20 @@ void launch_build_atomic_min(const uint64_t* R, uint64_t n, uint64_t* table, uin
                        R, n, table, tableSize - 1, probeLen, idxBase, ctr);
 }
 
-// Build from pre-packed (globalIdx << 32 | key) tuples (radix-sharded input after the
+// Build from pre-packed (globalIdx << (32 - strip) | key') tuples (radix-sharded input after the
 // exchange, hj_shard_scatter_dev). Same protocol, priority = global index.
 __global__ void __launch_bounds__(kBlock)
 k_build_packed(const uint64_t* __restrict__ P, uint64_t n, uint64_t* __restrict__ table,
-               uint64_t homeMask, uint32_t homeShift, uint32_t probeLen, Counters* __restrict__ ctr)
+               uint64_t homeMask, uint32_t strip, uint32_t shard, uint32_t probeLen, Counters* __restrict__ ctr)
 {
     unsigned long long drops = 0, dropSum = 0, inSum = 0, bad = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
         const uint64_t p = P[i];
-        const uint32_t key = (uint32_t)p;
+        const uint32_t kp = slot_key(p, strip);
+        const uint64_t key = full_key(kp, strip, shard);
         inSum += key;
         if (key == 0) { bad += 1; continue; }
-        insert_priority(table, homeMask, homeShift, probeLen, p, (key >> homeShift) & homeMask, probeLen, drops, dropSum);
+        insert_priority(table, homeMask, strip, shard, probeLen, p, kp & homeMask, probeLen, drops, dropSum);
     }
     flush_counter(&ctr->conflicts, drops);
     flush_counter(&ctr->conflictSum, dropSum);
@@ -169,22 +168,25 @@ k_build_packed(const uint64_t* __restrict__ P, uint64_t n, uint64_t* __restrict_
 }
 
 void launch_build_packed(const uint64_t* packed, uint64_t n, uint64_t* table, uint64_t tableSize,
-                         uint32_t homeShift, uint32_t probeLen, Counters* ctr, hipStream_t s)
+                         uint32_t strip, uint32_t shard, uint32_t probeLen, Counters* ctr, hipStream_t s)
 {
     hipLaunchKernelGGL(k_build_packed, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s,
-                       packed, n, table, tableSize - 1, homeShift, probeLen, ctr);
+                       packed, n, table, tableSize - 1, strip, shard, probeLen, ctr);
 }
 
 // ---------------------------------------------------------------------------
 // probe
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t probe_one(uint64_t sk, const uint64_t* __restrict__ table,
-                                              uint64_t mask, uint32_t homeShift, uint32_t probeLen,
+                                              uint64_t mask, uint32_t strip, uint32_t probeLen,
                                               uint64_t validLo, uint64_t validHiEx)
 {
     // outside the valid range no stored tuple can have this home slot (hj_device.h, Counters)
-    const uint64_t home = (sk >> homeShift) & mask;
-    if (home < validLo || home >= validHiEx) return 0;
+    // a tuple with payload bits set can match nothing; S tuples of a shard carry that shard's low key bits
+    const uint32_t kp = (uint32_t)sk >> strip;
+    const uint64_t home = kp & mask;
+    if ((sk >> 32) != 0 || home < validLo || home >= validHiEx) return 0;
+    const uint32_t km = key_mask(strip);
     // NoCCHashBuild.hpp:70-79: walk at most probeLen consecutive slots from the
     // home slot, stop at the first empty one, count slots equal to the tuple.
     const uint64_t* p = table + home;
@@ -192,15 +194,15 @@ __device__ __forceinline__ uint32_t probe_one(uint64_t sk, const uint64_t* __res
     if (probeLen == 4) {
         const uint64_t a = p[0], b = p[1], c = p[2], d = p[3];  // slack slots make this safe
         const bool ea = a != kEmpty, eb = ea && b != kEmpty, ec = eb && c != kEmpty, ed = ec && d != kEmpty;
-        m += (ea && (uint64_t)(uint32_t)a == sk);
-        m += (eb && (uint64_t)(uint32_t)b == sk);
-        m += (ec && (uint64_t)(uint32_t)c == sk);
-        m += (ed && (uint64_t)(uint32_t)d == sk);
+        m += (ea && ((uint32_t)a & km) == kp);
+        m += (eb && ((uint32_t)b & km) == kp);
+        m += (ec && ((uint32_t)c & km) == kp);
+        m += (ed && ((uint32_t)d & km) == kp);
     } else {
         for (uint32_t j = 0; j < probeLen; ++j) {
             const uint64_t v = p[j];
             if (v == kEmpty) break;
-            m += ((uint64_t)(uint32_t)v == sk);
+            m += (((uint32_t)v & km) == kp);
         }
     }
     return m;
@@ -208,7 +210,7 @@ __device__ __forceinline__ uint32_t probe_one(uint64_t sk, const uint64_t* __res
 
 __global__ void __launch_bounds__(kBlock)
 k_probe(const uint64_t* __restrict__ S, uint64_t n, const uint64_t* __restrict__ table, uint64_t mask,
-        uint32_t homeShift, uint32_t probeLen, Counters* __restrict__ ctr)
+        uint32_t strip, uint32_t probeLen, Counters* __restrict__ ctr)
 {
     unsigned long long matches = 0;
     const uint64_t validLo = ctr->validLo, validHiEx = ctr->validHiEx;
@@ -217,29 +219,29 @@ k_probe(const uint64_t* __restrict__ S, uint64_t n, const uint64_t* __restrict__
     const uint64_t nv = (n - head) >> 1;
     for (uint64_t v = (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (uint64_t)gridDim.x * kBlock) {
         const ulonglong2 t = S2[v];
-        matches += probe_one(t.x, table, mask, homeShift, probeLen, validLo, validHiEx);
-        matches += probe_one(t.y, table, mask, homeShift, probeLen, validLo, validHiEx);
+        matches += probe_one(t.x, table, mask, strip, probeLen, validLo, validHiEx);
+        matches += probe_one(t.y, table, mask, strip, probeLen, validLo, validHiEx);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (head) matches += probe_one(S[0], table, mask, homeShift, probeLen, validLo, validHiEx);
+        if (head) matches += probe_one(S[0], table, mask, strip, probeLen, validLo, validHiEx);
         const uint64_t tail = head + 2 * nv;
-        if (tail < n) matches += probe_one(S[tail], table, mask, homeShift, probeLen, validLo, validHiEx);
+        if (tail < n) matches += probe_one(S[tail], table, mask, strip, probeLen, validLo, validHiEx);
     }
     flush_counter(&ctr->matches, matches);
 }
 
 void launch_probe(const uint64_t* S, uint64_t n, const uint64_t* table, uint64_t tableSize,
-                  uint32_t homeShift, uint32_t probeLen, Counters* ctr, hipStream_t s)
+                  uint32_t strip, uint32_t probeLen, Counters* ctr, hipStream_t s)
 {
     hipLaunchKernelGGL(k_probe, dim3(grid_for(n / 2 + 1, kBlock)), dim3(kBlock), 0, s,
-                       S, n, table, tableSize - 1, homeShift, probeLen, ctr);
+                       S, n, table, tableSize - 1, strip, probeLen, ctr);
 }
 
 // ---------------------------------------------------------------------------
 // table checksums
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
-k_table_sums(const uint64_t* __restrict__ table, uint64_t tableSize, uint64_t halfSlots,
+k_table_sums(const uint64_t* __restrict__ table, uint64_t tableSize, uint64_t halfSlots, uint32_t strip, uint32_t shard,
              Counters* __restrict__ ctr)
 {
     unsigned long long half = 0, full = 0;
@@ -251,8 +253,8 @@ k_table_sums(const uint64_t* __restrict__ table, uint64_t tableSize, uint64_t ha
     const uint64_t nv = hi >> 1;
     for (uint64_t v = (lo >> 1) + (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (uint64_t)gridDim.x * kBlock) {
         const ulonglong2 t = t2[v];
-        const uint64_t a = (t.x == kEmpty) ? 0 : (uint32_t)t.x;
-        const uint64_t b = (t.y == kEmpty) ? 0 : (uint32_t)t.y;
+        const uint64_t a = (t.x == kEmpty) ? 0 : full_key(slot_key(t.x, strip), strip, shard);
+        const uint64_t b = (t.y == kEmpty) ? 0 : full_key(slot_key(t.y, strip), strip, shard);
         full += a + b;
         if (2 * v < halfSlots) half += a;
         if (2 * v + 1 < halfSlots) half += b;
@@ -261,11 +263,11 @@ k_table_sums(const uint64_t* __restrict__ table, uint64_t tableSize, uint64_t ha
     flush_counter(&ctr->tableSumFull, full);
 }
 
-void launch_table_sums(const uint64_t* table, uint64_t tableSize, uint64_t halfSlots, Counters* ctr,
-                       hipStream_t s)
+void launch_table_sums(const uint64_t* table, uint64_t tableSize, uint64_t halfSlots, uint32_t strip, uint32_t shard,
+                       Counters* ctr, hipStream_t s)
 {
     hipLaunchKernelGGL(k_table_sums, dim3(grid_for(tableSize / 2, kBlock * 4)), dim3(kBlock), 0, s,
-                       table, tableSize, halfSlots, ctr);
+                       table, tableSize, halfSlots, strip, shard, ctr);
 }
 
 __global__ void k_set_full_range(uint64_t tableSize, Counters* __restrict__ ctr)

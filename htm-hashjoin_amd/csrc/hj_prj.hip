@@ -40,7 +40,8 @@ struct PassParams {
     uint32_t chunkLen;          // multiple of kTile
     const uint32_t* chunkBase;  // [nSeg + 1] exclusive prefix of chunks per segment
     uint32_t shift, fan;        // bin = (key >> shift) & (fan - 1)
-    uint64_t packIdxBase;       // ~0: tuples move unchanged; else output = (packIdxBase + i) << 32 | key
+    uint64_t packIdxBase;       // ~0: tuples move unchanged; else output = (packIdxBase + i) << (32 - strip) | key >> strip
+    uint32_t strip;             // (slot format of hj_device.h)
 };
 
 // chunkBase[s] = sum_{t<s} ceil(len_t / chunkLen). nSeg <= 256: one thread.
@@ -265,20 +266,15 @@ k_radix_scatter(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, Pas
         for (int k = 0; k < kTileVec; ++k) {
             const uint64_t i = tb + 2 * ((uint64_t)k * kBlock + threadIdx.x);
             ulonglong2 t = cur[k];
-            if (p.packIdxBase != ~0ull) {   // shard scatter: the input index travels above the key
-                t.x = ((p.packIdxBase + i) << 32) | (uint32_t)t.x;
-                t.y = ((p.packIdxBase + i + 1) << 32) | (uint32_t)t.y;
+            const uint32_t binx = ((uint32_t)t.x >> p.shift) & fmask, biny = ((uint32_t)t.y >> p.shift) & fmask;
+            if (p.packIdxBase != ~0ull) {   // shard scatter: the input index travels above the (stripped) key
+                t.x = ((p.packIdxBase + i) << (32 - p.strip)) | ((uint32_t)t.x >> p.strip);
+                t.y = ((p.packIdxBase + i + 1) << (32 - p.strip)) | ((uint32_t)t.y >> p.strip);
             }
             tv[2 * k] = t.x; tv[2 * k + 1] = t.y;
             br[2 * k] = br[2 * k + 1] = 0xFFFFFFFFu;
-            if (i >= r.begin && i < r.end) {
-                const uint32_t bin = ((uint32_t)t.x >> p.shift) & fmask;
-                br[2 * k] = (bin << 16) | atomicAdd(&tileCnt[bin], 1u);
-            }
-            if (i + 1 >= r.begin && i + 1 < r.end) {
-                const uint32_t bin = ((uint32_t)t.y >> p.shift) & fmask;
-                br[2 * k + 1] = (bin << 16) | atomicAdd(&tileCnt[bin], 1u);
-            }
+            if (i >= r.begin && i < r.end) br[2 * k] = (binx << 16) | atomicAdd(&tileCnt[binx], 1u);
+            if (i + 1 >= r.begin && i + 1 < r.end) br[2 * k + 1] = (biny << 16) | atomicAdd(&tileCnt[biny], 1u);
         }
         __syncthreads();
         {   // exclusive scan of tileCnt[0..fan) (fan <= 256 = one value per thread)
@@ -298,7 +294,16 @@ k_radix_scatter(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, Pas
             const uint32_t q = (uint32_t)k * kBlock + threadIdx.x;
             if (q < valid) {
                 const uint64_t t = stage[q];
-                const uint32_t bin = ((uint32_t)t >> p.shift) & fmask;
+                // bin of staged position q: packed tuples no longer carry their bin bits, so look it up
+                // (largest bin with tileOff[bin] <= q; fan <= 256 -> 8 steps of binary search in LDS)
+                uint32_t bin;
+                if (p.packIdxBase == ~0ull) {
+                    bin = ((uint32_t)t >> p.shift) & fmask;
+                } else {
+                    uint32_t lo = 0, hi = p.fan;
+                    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tileOff[mid] <= q) lo = mid; else hi = mid; }
+                    bin = lo;
+                }
                 out[cursor[bin] + (q - tileOff[bin])] = t;
             }
         }
@@ -560,7 +565,7 @@ void run_pass(const uint64_t* in, uint64_t* out, uint64_t n, const uint32_t* seg
     const uint32_t fan = 1u << bits;
     const PassLayout l = pass_layout(n, nSeg, fan);
     hipLaunchKernelGGL(k_chunk_base, dim3(1), dim3(64), 0, s, segIn, nSeg, l.chunkLen, w.chunkBase);
-    PassParams p{segIn, nSeg, l.chunkLen, w.chunkBase, shift, fan, ~0ull};
+    PassParams p{segIn, nSeg, l.chunkLen, w.chunkBase, shift, fan, ~0ull, 0u};
     // entries past the live chunks must be zero for the scan to be a prefix of live data only
     hipMemsetAsync(w.hist, 0, sizeof(uint32_t) * l.histEntries, s);
     hipLaunchKernelGGL(k_radix_hist, dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s, in, p, w.hist);
@@ -652,7 +657,7 @@ void launch_shard_hist(const uint64_t* in, uint64_t n, uint32_t nShards, void* w
     const PassLayout l = pass_layout(n, 1, nShards);
     hipLaunchKernelGGL(k_init_seg, dim3(1), dim3(64), 0, s, w.seg0, (uint32_t)n);
     hipLaunchKernelGGL(k_chunk_base, dim3(1), dim3(64), 0, s, w.seg0, 1u, l.chunkLen, w.chunkBase);
-    PassParams p{w.seg0, 1u, l.chunkLen, w.chunkBase, 0u, nShards, ~0ull};
+    PassParams p{w.seg0, 1u, l.chunkLen, w.chunkBase, 0u, nShards, ~0ull, 0u};
     (void)hipMemsetAsync(w.hist, 0, sizeof(uint32_t) * l.histEntries, s);
     hipLaunchKernelGGL(k_radix_hist, dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s, in, p, w.hist);
     hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)l.scanBlocks), dim3(kBlock), 0, s, w.hist, l.histEntries, w.sums);
@@ -663,11 +668,11 @@ void launch_shard_hist(const uint64_t* in, uint64_t n, uint32_t nShards, void* w
 }
 
 void launch_shard_scatter_ordered(const uint64_t* in, uint64_t n, uint32_t nShards, void* work, uint64_t packIdxBase,
-                                  uint64_t* out, hipStream_t s)
+                                  uint32_t strip, uint64_t* out, hipStream_t s)
 {
     const ShardWork w = shard_carve(work, n, nShards);
     const PassLayout l = pass_layout(n, 1, nShards);
-    PassParams p{w.seg0, 1u, l.chunkLen, w.chunkBase, 0u, nShards, packIdxBase};
+    PassParams p{w.seg0, 1u, l.chunkLen, w.chunkBase, 0u, nShards, packIdxBase, strip};
     hipLaunchKernelGGL(k_radix_scatter, dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s, in, out, p, w.hist);
 }
 

@@ -149,13 +149,13 @@ class HashJoinContext:
         self._check(lib.hj_shard_histogram_dev(self._h, C.c_void_p(d_in), n, n_shards, mode, table_size,
                                                C.c_void_p(d_counts)))
 
-    def shard_scatter(self, d_in, n, n_shards, mode, table_size, d_counts, pack_idx_base, d_out):
+    def shard_scatter(self, d_in, n, n_shards, mode, table_size, d_counts, pack_idx_base, strip_bits, d_out):
         base = 0xFFFFFFFFFFFFFFFF if pack_idx_base is None else pack_idx_base
         self._check(lib.hj_shard_scatter_dev(self._h, C.c_void_p(d_in), n, n_shards, mode, table_size,
-                                             C.c_void_p(d_counts), base, C.c_void_p(d_out)))
+                                             C.c_void_p(d_counts), base, strip_bits, C.c_void_p(d_out)))
 
-    def build_packed(self, d_packed, n, home_shift, table_size):
-        self._check(lib.hj_build_packed_dev(self._h, C.c_void_p(d_packed), n, home_shift, table_size))
+    def build_packed(self, d_packed, n, strip_bits, shard_id, table_size):
+        self._check(lib.hj_build_packed_dev(self._h, C.c_void_p(d_packed), n, strip_bits, shard_id, table_size))
 
 
 def _operator(algo, relR, rSize, relS, sSize, device, **kw):

@@ -7,8 +7,10 @@ piece of R and of S. Per join:
   1. histogram   destination of a tuple = key & (G-1)   (HASH_BIT_MODULO on the low bits,
                  mc/src/parallel_radix_join.c:59)                     -> hj_shard_histogram_dev
   2. counts      one all_to_all_single of the G per-destination counts (R and S together)
-  3. scatter     tuples grouped by destination; an R tuple travels as (globalIndex << 32 | key) so
-                 that index priority survives the exchange           -> hj_shard_scatter_dev
+  3. scatter     tuples grouped by destination; an R tuple travels as (globalIndex << (32-s) | key >> s),
+                 s = log2 G: index priority survives the exchange, and the shard bits of the key --
+                 the same for every tuple of a destination -- give their room to the index, which
+                 may use 32+s bits (8 x 2^30 tuples fit)                 -> hj_shard_scatter_dev
   4. exchange    one all_to_all_single per relation (async: R's exchange overlaps the split of S, S's
                  exchange overlaps the local build); every rank sends 1/G of its tuples to every peer
                  directly, so all xGMI links carry traffic at once
@@ -23,8 +25,8 @@ input order with the reference's probe budget; the test suite restates exactly t
 compares bit-exactly (tests/test_sharded_gloo.py). For G = 1 this is the single-GPU operator. For unique keys
 (sorted / shuffle / local_shuffle) the totals equal the single-table result (conflicts 0,
 matches |R|); for duplicate keys they are the radix-partitioned variant of it, a different but
-equally deterministic number (linear-probe neighbourhoods differ once the table is split). Sizes: total |R| < 2^32 (the global
-index is 32 bits).
+equally deterministic number (linear-probe neighbourhoods differ once the table is split). Sizes: total
+|R| < 2^(32 + log2 G), 2^31 per rank.
 
 The compute engine is injected: HipShardEngine (below) is the product path and the only engine in
 this package; the CPU tests inject a checker-backed engine of their own to exercise this file's
@@ -64,10 +66,10 @@ class HipShardEngine:
         self.ctx.shard_histogram(t.data_ptr(), t.numel(), n_shards, 0, 0, counts.data_ptr())
         return counts
 
-    def scatter(self, t, n_shards, counts, pack_idx_base):
+    def scatter(self, t, n_shards, counts, pack_idx_base, strip_bits):
         out = self.empty(t.numel())
         self.ctx.shard_scatter(t.data_ptr(), t.numel(), n_shards, 0, 0, counts.data_ptr(), pack_idx_base,
-                               out.data_ptr())
+                               strip_bits, out.data_ptr())
         return out
 
     def reserve(self, table_size, max_r, max_s):
@@ -81,8 +83,8 @@ class HipShardEngine:
             self.ctx.reserve("atomic", r, max_s, buildVariant=self.build_variant)
             self._reserved = key
 
-    def build(self, r_packed, home_shift, table_size):
-        self.ctx.build_packed(r_packed.data_ptr(), r_packed.numel(), home_shift, table_size)
+    def build(self, r_packed, strip_bits, shard_id, table_size):
+        self.ctx.build_packed(r_packed.data_ptr(), r_packed.numel(), strip_bits, shard_id, table_size)
 
     def probe(self, s_keys):
         self.ctx.probe(s_keys.data_ptr(), s_keys.numel())
@@ -135,14 +137,14 @@ class ShardedJoin:
         cnt_r = e.histogram(r_local, self.world)
         cnt_s = e.histogram(s_local, self.world)
         send_r, send_s, recv_r, recv_s = self._exchange_counts(cnt_r, cnt_s)
-        out_r = e.scatter(r_local, self.world, cnt_r, idx_base)     # (gidx << 32 | key)
+        out_r = e.scatter(r_local, self.world, cnt_r, idx_base, self.strip)     # (gidx << (32-s) | key >> s)
         got_r, work_r = self._exchange_async(out_r, send_r, recv_r)
-        out_s = e.scatter(s_local, self.world, cnt_s, None)         # unchanged tuples
+        out_s = e.scatter(s_local, self.world, cnt_s, None, 0)                  # unchanged tuples
         got_s, work_s = self._exchange_async(out_s, send_s, recv_s)
         e.reserve(table_size, got_r.numel(), got_s.numel())
         if work_r is not None:
             work_r.wait()
-        e.build(got_r, self.strip, table_size)
+        e.build(got_r, self.strip, self.rank, table_size)
         if work_s is not None:
             work_s.wait()
         e.probe(got_s)
@@ -165,24 +167,22 @@ class ShardedJoin:
 
 
 def bench_sharded(args, torch, dist, hj, rank, world, local_rank):
-    """bench.py's N > 1 leg. STRONG scaling: the total stays the N=1 workload (|R| = |S| = 2^log2n tuples,
-    the metric's configuration), each rank holding a 1/N contiguous piece. (The global input index that
-    travels with every R tuple is 32 bits, so total |R| must stay below 2^32; weak scaling at 2^30 tuples
-    per GPU would need 33 bits at N = 8.)"""
+    """bench.py's N > 1 leg. Default = WEAK scaling: every rank holds 2^log2n tuples of R and of S (the N=1
+    workload per GPU; 8 GPUs x 2^30 = BASELINE config 4); --strong keeps the N=1 total and splits it.
+    Rank g's piece = DataGen over its own key range (g*n, (g+1)*n]: globally the near-sorted relation the
+    reference generates, drawn piecewise (a rank cannot afford the serial rand() stream of its
+    neighbours). Keys are 32 bits, so once the global range passes 2^32 - 1 it wraps (keys then repeat across
+    ranks, which the operator handles like any duplicate key)."""
     strip = _log2(world)
-    n_total = 1 << args.log2n
-    if args.log2n > 31:
-        raise SystemExit("total |R| must stay below 2^32 tuples (32-bit global index)")
-    n = n_total >> strip                            # per rank
-    # Rank g's piece = DataGen over its own key range [g*n+1, (g+1)*n]: globally this is the near-sorted
-    # relation the reference generates, drawn piecewise (a rank cannot afford the serial 2^30 rand() stream
-    # of its neighbours).
+    n = (1 << args.log2n) >> (strip if args.strong else 0)          # tuples per rank and relation
     window = args.shuffle_range
+    wrap = (1 << 32) - 1
     R = hj.generate_data(args.dist, n, n, window)
-    R += np.uint64(rank * n)
+    R = ((R + np.uint64(rank * n) - np.uint64(1)) % np.uint64(wrap)) + np.uint64(1)
     r_local = torch.from_numpy(R.view("int64")).to(f"cuda:{local_rank}")
     del R
-    s_local = torch.arange(rank * n + 1, (rank + 1) * n + 1, dtype=torch.int64, device=f"cuda:{local_rank}")
+    s_local = torch.arange(rank * n, (rank + 1) * n, dtype=torch.int64, device=f"cuda:{local_rank}")
+    s_local = torch.remainder(s_local, wrap) + 1                     # generate_data("sorted") on the same key range
     eng = HipShardEngine(hj, torch, local_rank, build_variant=args.build_variant)
     job = ShardedJoin(eng, torch, dist, rank, world)
     table_size = 2 * n
@@ -203,22 +203,25 @@ def bench_sharded(args, torch, dist, hj, rank, world, local_rank):
     dt = float(t.item())
     res = job.result()
     total = 2 * n * world
-    unique = args.dist in ("sorted", "shuffle", "local_shuffle")
+    unique_domain = n * world <= wrap
+    unique = unique_domain and args.dist in ("sorted", "shuffle", "local_shuffle")
     line = {
         "metric": "Mtuples/sec build+probe, |R|=|S|=1B uint32, uniform vs local_shuffle",
         "value": total * args.steps / dt / 1e6, "unit": "Mtuples/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong" if args.strong else "weak",
         "vs_baseline": None, "dtype": "u64 tuples (u32 key), integer",
         "data": "synthetic (DataGen restatement per rank on its own key range)",
-        "config": {"workload": f"radix-sharded open-addressing build+probe over {world} GPUs, total |R|=|S|=2^{args.log2n} "
-                               f"({n} per GPU), dataDistr={args.dist} W={window}; step = destination histogram + "
-                               "order-preserving scatter + all-to-all (R and S) + local table clear/build/probe + "
-                               "counter all-reduce", "algo": "atomic", "rSize": n * world,
+        "config": {"workload": f"radix-sharded open-addressing build+probe over {world} GPUs, |R|=|S|={n} per GPU "
+                               f"({n * world} in total), dataDistr={args.dist} W={window}; step = destination histogram + "
+                               "order-preserving scatter + all-to-all (R and S, overlapped) + local table build/probe",
+                   "algo": "atomic", "rSize": n * world,
                    "sSize": n * world, "per_gpu_rSize": n, "dataDistr": args.dist, "shuffleRange": window,
                    "parallelism": f"radix{world}"},
         "result": {k: res[k] for k in ("conflicts", "totalMatches", "inputSum", "buildDeferred")},
-        "checks": {"matches_plus_conflicts_eq_rSize": res["totalMatches"] + res["conflicts"] == n * world,
-                   "unique_keys_all_match": (res["totalMatches"] == n * world) if unique else None},
+        "checks": {"matches_plus_conflicts_eq_rSize": (res["totalMatches"] + res["conflicts"] == n * world) if unique_domain else None,
+                   "unique_keys_all_match": (res["totalMatches"] == n * world) if unique else None,
+                   "tableSum_plus_conflictSum_eq_inputSum": res["tableSumFull"] + res["conflictSum"] == res["inputSum"]},
         "exchange": res["exchange"], "local_kernel_us": {k: res["local"][k] for k in ("clear_us", "build_us", "probe_us")},
         "local_build_variant": res["local"]["buildVariant"],
         "roofline": None, "cpu_baseline": None,

@@ -168,23 +168,25 @@ int hj_shard_histogram_dev(hj_ctx *ctx, const uint64_t *dIn, uint64_t n,
  * hj_shard_histogram_dev on the same (dIn, n). The input order is preserved
  * chunk-wise inside every destination (scan-based cursors; only the 4096 tuples
  * of a tile may be permuted among themselves), so near-sorted inputs stay
- * near-sorted. With packIdxBase == UINT64_MAX tuples are copied unchanged;
- * otherwise each output tuple is ((packIdxBase + i) << 32) | key, i.e. the
- * tuple's global input index travels with it so that index priority survives
- * the exchange (packIdxBase + n must fit 32 bits). Async. */
+ * near-sorted. With packIdxBase == UINT64_MAX tuples are copied unchanged
+ * (stripBits ignored). Otherwise each output tuple is
+ *     ((packIdxBase + i) << (32 - stripBits)) | (key >> stripBits):
+ * the tuple's global input index travels with it so that index priority
+ * survives the exchange, and the low stripBits key bits -- the shard number,
+ * identical for every tuple of a destination -- give their room to the index,
+ * which may therefore use 32 + stripBits bits (8 GPUs x 2^30 tuples fit). Async. */
 int hj_shard_scatter_dev(hj_ctx *ctx, const uint64_t *dIn, uint64_t n,
                          uint32_t nShards, uint32_t mode, uint64_t tableSize,
                          const uint64_t *dCounts, uint64_t packIdxBase,
-                         uint64_t *dOut);
-/* Like hj_build_dev for tuples that are already (globalIdx << 32 | key) (the
- * output of hj_shard_scatter_dev after the exchange), into a table of tableSize
- * slots (a power of two, reserved via hj_reserve(rSize = tableSize/2)). The home
- * slot of a key is (key >> homeShift) & (tableSize-1): with radix sharding the
- * low log2(nShards) key bits are equal for all tuples of a shard and are left
- * out of the slot number. hj_probe_dev afterwards takes plain tuples (value = key)
- * and uses the same homeShift. */
+                         uint32_t stripBits, uint64_t *dOut);
+/* Like hj_build_dev for tuples in the packed format above (the output of
+ * hj_shard_scatter_dev after the exchange), into a table of tableSize slots (a
+ * power of two, reserved via hj_reserve(rSize = tableSize/2)). shardId is the
+ * value of the stripped key bits (this rank's number); the home slot of a key
+ * is (key >> stripBits) & (tableSize-1). hj_probe_dev afterwards takes plain
+ * tuples (value = key) whose low stripBits bits equal shardId. */
 int hj_build_packed_dev(hj_ctx *ctx, const uint64_t *dPacked, uint64_t n,
-                        uint32_t homeShift, uint64_t tableSize);
+                        uint32_t stripBits, uint32_t shardId, uint64_t tableSize);
 
 /* ---- device memory for hosts without a HIP runtime of their own ----------- */
 int hj_dev_alloc(hj_ctx *ctx, uint64_t bytes, void **dptr);

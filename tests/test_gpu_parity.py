@@ -257,26 +257,32 @@ def test_sharded_kernels_on_one_gpu(ctx, G, dist, window, variant):
     S = oracle.relS_for(dist, R)
     want = oracle.sharded_reference(R, S, G)
     strip = G.bit_length() - 1
+    # index base beyond 32 bits when the format allows it (strip >= 1): the 8 x 2^30 case needs 33 bits
+    BASE = (1 << 32) + 12345 if strip >= 1 else 0
     inbox_r = [[] for _ in range(G)]
     inbox_s = [[] for _ in range(G)]
     with hj.HashJoinContext(0) as c:
         d_in = c.dev_alloc(n_local * 8); d_out = c.dev_alloc(n_local * 8); d_cnt = c.dev_alloc(G * 8)
         for src in range(G):
-            for rel, inbox, base in ((R, inbox_r, src * n_local), (S, inbox_s, None)):
+            for rel, inbox, base in ((R, inbox_r, BASE + src * n_local), (S, inbox_s, None)):
                 piece = rel[src * n_local:(src + 1) * n_local]
                 c.copy_h2d(d_in, piece)
                 c.shard_histogram(d_in, n_local, G, 0, 0, d_cnt)
-                c.shard_scatter(d_in, n_local, G, 0, 0, d_cnt, base, d_out)
+                c.shard_scatter(d_in, n_local, G, 0, 0, d_cnt, base, strip if base is not None else 0, d_out)
                 cnt = np.empty(G, dtype=np.uint64); c.copy_d2h(cnt, d_cnt)
                 out = np.empty(n_local, dtype=np.uint64); c.copy_d2h(out, d_out)
                 assert np.array_equal(cnt, np.bincount((piece & np.uint64(G - 1)).astype(np.int64), minlength=G).astype(np.uint64))
                 off = 0
                 for g in range(G):
                     seg = out[off:off + int(cnt[g])]; off += int(cnt[g])
-                    assert np.all((seg & np.uint64(G - 1)) == g)                   # grouped by destination
-                    if base is not None:                                           # index packed above the key
-                        idx = (seg >> np.uint64(32)).astype(np.int64)
-                        assert np.array_equal(np.sort(idx), base + np.nonzero((piece & np.uint64(G - 1)) == g)[0])
+                    if base is None:
+                        assert np.all((seg & np.uint64(G - 1)) == g)               # grouped by destination, unchanged
+                    else:                                                          # index packed above the stripped key
+                        idx = (seg >> np.uint64(32 - strip)).astype(np.int64)
+                        sel = np.nonzero((piece & np.uint64(G - 1)) == g)[0]
+                        assert np.array_equal(np.sort(idx), base + sel)
+                        keyp = seg & np.uint64(0xFFFFFFFF >> strip)
+                        assert np.array_equal(np.sort((keyp << np.uint64(strip)) | np.uint64(g)), np.sort(piece[sel]))
                         # input order is preserved up to permutations inside one 4096-tuple tile
                         if idx.size:
                             assert np.all(idx - np.maximum.accumulate(idx) > -4096)
@@ -294,7 +300,7 @@ def test_sharded_kernels_on_one_gpu(ctx, G, dist, window, variant):
             c.reserve("atomic", r, got_s.size, buildVariant=variant)
             d_r = c.dev_alloc(max(got_r.size, 1) * 8); d_s = c.dev_alloc(max(got_s.size, 1) * 8)
             c.copy_h2d(d_r, got_r); c.copy_h2d(d_s, got_s)
-            c.build_packed(d_r, got_r.size, strip, table_size)
+            c.build_packed(d_r, got_r.size, strip, g, table_size)
             c.probe(d_s, got_s.size)
             c.checksums()
             res = c.fetch()

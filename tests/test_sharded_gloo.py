@@ -27,7 +27,7 @@ class OracleShardEngine:
         k = t.numpy().view(np.uint64)
         return torch.from_numpy(np.bincount((k & np.uint64(n_shards - 1)).astype(np.int64), minlength=n_shards)).to(torch.int64)
 
-    def scatter(self, t, n_shards, counts, pack_idx_base):
+    def scatter(self, t, n_shards, counts, pack_idx_base, strip_bits):
         k = t.numpy().view(np.uint64)
         dest = (k & np.uint64(n_shards - 1)).astype(np.int64)
         order = np.argsort(dest, kind="stable")[::1]
@@ -38,16 +38,17 @@ class OracleShardEngine:
         kp = k.copy()
         if pack_idx_base is not None:
             idx = np.arange(len(k), dtype=np.uint64) + np.uint64(pack_idx_base)
-            kp = (idx << np.uint64(32)) | kp
+            kp = (idx << np.uint64(32 - strip_bits)) | (k >> np.uint64(strip_bits))
         return torch.from_numpy(kp[order].view(np.int64).copy())
 
     def reserve(self, table_size, max_r, max_s):
         pass
 
-    def build(self, r_packed, home_shift, table_size):
+    def build(self, r_packed, strip_bits, shard_id, table_size):
         p = r_packed.numpy().view(np.uint64)
         p = np.sort(p)                                  # global index is the high field: sort = global input order
-        self._built = (p & np.uint64(0xFFFFFFFF), home_shift, table_size)
+        keys = ((p & np.uint64(0xFFFFFFFF >> strip_bits)) << np.uint64(strip_bits)) | np.uint64(shard_id)
+        self._built = (keys, strip_bits, table_size)
 
     def probe(self, s_keys):
         keys, home_shift, table_size = self._built
@@ -67,7 +68,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, dist_name, window, n_local, out):
+def _worker(rank, world, port, dist_name, window, n_local, out, idx_offset=0):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import htm_hashjoin_amd as hj
@@ -78,7 +79,7 @@ def _worker(rank, world, port, dist_name, window, n_local, out):
     r_local = torch.from_numpy(R[rank * n_local:(rank + 1) * n_local].view(np.int64).copy())
     s_local = torch.from_numpy(S[rank * n_local:(rank + 1) * n_local].view(np.int64).copy())
     job = ShardedJoin(OracleShardEngine(), torch, dist, rank, world)
-    job.step(r_local, s_local, rank * n_local, 2 * n_local)
+    job.step(r_local, s_local, idx_offset + rank * n_local, 2 * n_local)
     res = job.result()
     if rank == 0:
         out.put({k: res[k] for k in ("conflicts", "totalMatches", "inputSum", "tableSumFull", "conflictSum")})
@@ -91,7 +92,9 @@ def test_sharded_join_matches_sharded_reference(world, dist_name, window):
     n_local = 1 << 12
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, PORT[0], dist_name, window, n_local, q))
+    # global indices beyond 32 bits (what 8 GPUs x 2^30 tuples need) whenever the packed format has room
+    idx_offset = (1 << 32) + 7 if dist_name == "uniform" else 0
+    procs = [ctx.Process(target=_worker, args=(r, world, PORT[0], dist_name, window, n_local, q, idx_offset))
              for r in range(world)]
     for p in procs:
         p.start()
