@@ -11,9 +11,10 @@ piece of R and of S. Per join:
                  s = log2 G: index priority survives the exchange, and the shard bits of the key --
                  the same for every tuple of a destination -- give their room to the index, which
                  may use 32+s bits (8 x 2^30 tuples fit)                 -> hj_shard_scatter_dev
-  4. exchange    one all_to_all_single per relation (async: R's exchange overlaps the split of S, S's
-                 exchange overlaps the local build); every rank sends 1/G of its tuples to every peer
-                 directly, so all xGMI links carry traffic at once
+  4. exchange    one all-to-all per relation, issued as a batch of direct pairwise sends/receives of at
+                 most 512 MiB (async: R's exchange overlaps the split of S, S's exchange overlaps the
+                 local build); every rank sends 1/G of its tuples to every peer directly, so all xGMI
+                 links carry traffic at once (no ring)
   5. local join  open-addressing build of the received R into a table of 2*|R_local| slots by
                  global index priority, home slot = (key >> log2 G) & mask (the shard bits are the
                  same for every local tuple), probe with the received S
@@ -118,17 +119,40 @@ class ShardedJoin:
         got = recv.cpu().tolist()
         return [s[0] for s in send], [s[1] for s in send], [g[0] for g in got], [g[1] for g in got]
 
+    # Largest single message, in tuples. RCCL (ROCm 7.0 wheel of torch 2.10) delivered only half of an
+    # all_to_all_single whose per-peer message reached 2 GiB (tools/dbg/a2a_check.py: 2^27 int64 fine, 2^28
+    # half missing), so the exchange is issued as point-to-point messages of at most 512 MiB.
+    max_msg_tuples = 1 << 26
+
     def _exchange_async(self, send, send_counts, recv_counts):
-        """Starts the all-to-all of one relation; returns (output tensor, work handle or None). With NCCL/RCCL the
-        collective runs on the backend's own stream behind the kernels already enqueued on the current stream,
-        and work.wait() only makes the current stream wait for it (no host block)."""
+        """Starts the exchange of one relation: direct pairwise sends (every peer at once, so all xGMI links
+        carry traffic; no ring), batched into one group. Returns (output tensor, work handles). With NCCL/RCCL
+        the transfers run on the backend's stream behind the kernels already enqueued on the current stream,
+        and work.wait() only makes the current stream wait (no host block)."""
         out = self.e.empty(sum(recv_counts))
-        if self.dist is not None:
-            work = self.dist.all_to_all_single(out, send, output_split_sizes=recv_counts, input_split_sizes=send_counts,
-                                               async_op=True)
-            return out, work
-        out.copy_(send)
-        return out, None
+        so = [0]
+        for c in send_counts:
+            so.append(so[-1] + c)
+        ro = [0]
+        for c in recv_counts:
+            ro.append(ro[-1] + c)
+        me = self.rank
+        if recv_counts[me]:
+            out[ro[me]:ro[me + 1]].copy_(send[so[me]:so[me + 1]])           # my own share never leaves the GPU
+        works = []
+        if self.dist is not None and self.world > 1:
+            step = self.max_msg_tuples
+            ops = []
+            for off in range(1, self.world):                                  # staggered peer order
+                d = (me + off) % self.world
+                for k in range(0, send_counts[d], step):
+                    ops.append(self.dist.P2POp(self.dist.isend, send[so[d] + k: so[d] + min(k + step, send_counts[d])], d))
+                src = (me - off) % self.world
+                for k in range(0, recv_counts[src], step):
+                    ops.append(self.dist.P2POp(self.dist.irecv, out[ro[src] + k: ro[src] + min(k + step, recv_counts[src])], src))
+            if ops:
+                works = self.dist.batch_isend_irecv(ops)
+        return out, works
 
     def step(self, r_local, s_local, idx_base, table_size):
         """One build+probe over this rank's shards. Everything is enqueued; call result() to sync.
@@ -142,11 +166,11 @@ class ShardedJoin:
         out_s = e.scatter(s_local, self.world, cnt_s, None, 0)                  # unchanged tuples
         got_s, work_s = self._exchange_async(out_s, send_s, recv_s)
         e.reserve(table_size, got_r.numel(), got_s.numel())
-        if work_r is not None:
-            work_r.wait()
+        for w in work_r:
+            w.wait()
         e.build(got_r, self.strip, self.rank, table_size)
-        if work_s is not None:
-            work_s.wait()
+        for w in work_s:
+            w.wait()
         e.probe(got_s)
         self.last = {"sent_r": sum(send_r) - send_r[self.rank], "sent_s": sum(send_s) - send_s[self.rank],
                      "recv_r": got_r.numel(), "recv_s": got_s.numel()}

@@ -79,6 +79,7 @@ def _worker(rank, world, port, dist_name, window, n_local, out, idx_offset=0):
     r_local = torch.from_numpy(R[rank * n_local:(rank + 1) * n_local].view(np.int64).copy())
     s_local = torch.from_numpy(S[rank * n_local:(rank + 1) * n_local].view(np.int64).copy())
     job = ShardedJoin(OracleShardEngine(), torch, dist, rank, world)
+    job.max_msg_tuples = 700            # force the exchange into several messages per peer
     job.step(r_local, s_local, idx_offset + rank * n_local, 2 * n_local)
     res = job.result()
     if rank == 0:
