@@ -245,7 +245,8 @@ int hj_reserve(hj_ctx* c, const hj_params* params, uint64_t rSize, uint64_t sSiz
     if (rc) return rc;
     if (params->buildVariant > 2) return fail(c, HJ_ERR_INVALID, "hj_reserve: buildVariant must be 0, 1 or 2");
     if (params->buildVariant != 1 && own_supported(2 * rSize)) {
-        const size_t ob = own_owner_bytes(2 * rSize), qb = own_queue_bytes(rSize);
+        // 1/8 headroom: a radix shard may receive slightly more than its nominal share (hj_build_packed_dev)
+        const size_t ob = own_owner_bytes(2 * rSize), qb = own_queue_bytes(rSize + rSize / 8);
         if (ob > c->capOwner) {
             if (c->ownerBuf) { HJ_HIP(c, hipFree(c->ownerBuf)); c->ownerBuf = nullptr; c->capOwner = 0; }
             HJ_HIP(c, hipMalloc(&c->ownerBuf, ob)); c->capOwner = ob;

@@ -79,7 +79,7 @@ class HipShardEngine:
             # the queue of the LDS-window build is sized from rSize: reserve for the larger of the
             # nominal share and what actually arrived
             r = table_size // 2
-            while r < max_r:
+            while r + r // 8 < max_r:       # hj_reserve keeps 1/8 headroom for uneven shards
                 r *= 2
             self.ctx.reserve("atomic", r, max_s, buildVariant=self.build_variant)
             self._reserved = key
