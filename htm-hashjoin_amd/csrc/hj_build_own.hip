@@ -14,17 +14,19 @@
 //            walks its chunk tile by tile and keeps a sliding window of the table
 //            (kWinSlots slots, 64 KiB) in LDS. The table is divided into blocks of
 //            kBlkSlots slots; a workgroup may only touch blocks it OWNS, and it
-//            claims a block (one atomicCAS on a small owner table) when the block
-//            enters its window. Inserts into owned blocks run the index-priority
+//            claims a block (one atomicCAS on a small owner table) lazily, the first
+//            time a tile needs it. Inserts into owned blocks run the index-priority
 //            protocol of hj_kernels.hip on LDS (ds_min_rtn_u64). When the window
 //            slides, finished blocks go to HBM as whole 4 KiB runs of plain
 //            16-byte stores. A tuple whose probe walk reaches a block that is not
 //            owned (lost claim at a chunk seam, key far from the window, spill
 //            past the window end) is "aborted": it is appended, with the slot it
 //            had reached, to a deferred queue.
-//   clear    k_clear_unowned: blocks nobody claimed are filled with the empty
-//            pattern (owned blocks were written whole in phase A, so the table is
-//            written exactly once).
+//   clear    k_finalize_range + k_clear_unowned: the block range any tuple can reach
+//            becomes the table's "valid range"; inside it, blocks nobody claimed are
+//            filled with the empty pattern (owned blocks were written whole in phase
+//            A, so every reachable slot is written exactly once); outside it the
+//            table is neither written nor, later, probed.
 //   phase B  k_build_deferred: the deferred tuples finish their probe walk with
 //            the global atomicMin protocol (the "serial retry" of the reference,
 //            except that it is parallel and order independent).

@@ -105,7 +105,7 @@ class ShardedJoin:
 
     def __init__(self, engine, torch, dist, rank, world):
         self.e, self.torch, self.dist, self.rank, self.world = engine, torch, dist, rank, world
-        self.strip = _log2(world)       # shard bits = homeShift of the local tables
+        self.strip = _log2(world)       # shard bits stripped from the keys of the local tables
         self.last = {}
 
     def _exchange_counts(self, cnt_r, cnt_s):
