@@ -247,17 +247,24 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
                 wb = nb;             // first window; blocks are claimed lazily below
                 haveWin = true;
             } else if (nb > wb) {
-                // retire blocks [wb, min(nb, wb+K)): owned ones go to HBM whole, then reset
+                // retire blocks [wb, min(nb, wb+K)): owned ones go to HBM whole (empties included), then their
+                // LDS copy is reset (ablation: this phase is 200 of 550 us at 2^27). ownedMask still describes
+                // the window of the previous tile, i.e. exactly the blocks that leave.
                 const uint32_t nRetire = (nb - wb) < kWinBlocks ? (nb - wb) : kWinBlocks;
-                for (uint32_t r = 0; r < nRetire; ++r) {
+                constexpr uint32_t kVecPerBlk = kBlkSlots / 2;                      // 256 x 16 B
+                constexpr uint32_t kRetireIter = kWinBlocks * kVecPerBlk / kOwnThreads;   // 8
+                // two blocks per pass: threads 0..255 take block r, 256..511 block r+1, one vector each
+                // (more vectors in flight per thread spill: the kernel sits at the 128-VGPR cap)
+                (void)kRetireIter;
+                const uint32_t half = threadIdx.x / kVecPerBlk, v = threadIdx.x % kVecPerBlk;
+                for (uint32_t r0 = 0; r0 < nRetire && !(ABL & 16); r0 += kOwnThreads / kVecPerBlk) {
+                    const uint32_t r = r0 + half;
                     const uint32_t blk = wb + r, ring = blk & (kWinBlocks - 1);
-                    if (owned[ring] == 1) {
-                        ulonglong2* dst = reinterpret_cast<ulonglong2*>(table + ((uint64_t)blk << kBlkShift));
-                        ulonglong2* src = reinterpret_cast<ulonglong2*>(win + ((uint64_t)ring << kBlkShift));
-                        for (uint32_t v = threadIdx.x; v < kBlkSlots / 2; v += kOwnThreads) {
-                            if (!(ABL & 4)) dst[v] = src[v];
-                            src[v] = make_ulonglong2(kEmpty, kEmpty);
-                        }
+                    if (r < nRetire && ((ownedMask >> ring) & 1u)) {
+                        ulonglong2* src = reinterpret_cast<ulonglong2*>(win + ((uint64_t)ring << kBlkShift)) + v;
+                        const ulonglong2 t = *src;
+                        if (!(ABL & 4)) reinterpret_cast<ulonglong2*>(table + ((uint64_t)blk << kBlkShift))[v] = t;
+                        *src = make_ulonglong2(kEmpty, kEmpty);
                     }
                 }
                 __syncthreads();
@@ -274,7 +281,7 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
         // across a chunk seam must not take a whole block from the neighbour chunk that fills it
         // (they are deferred instead). Elsewhere any touched block is claimed.
         const bool seamTile = firstTile || lastTile;
-        if (haveWin) {
+        if (haveWin && !(ABL & 8)) {
 #pragma unroll
             for (int j = 0; j < kPerThread; ++j) {
                 const uint32_t home = (klo[j] & kmask) & mask32;
@@ -307,7 +314,8 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
             for (int off = 8; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(mx, off, 64); mx = o > mx ? o : mx; }
             if (t < kWinBlocks) {
                 need[t] = 0;
-                if (c && (c >= 0x10000u || c * 4 >= mx) && owned[t] == 0) {
+                if ((ABL & 8) && owned[t] == 0) owned[t] = 1u;
+                if (!(ABL & 8) && c && (c >= 0x10000u || c * 4 >= mx) && owned[t] == 0) {
                     const uint32_t blk = wb + ((t - wb) & (kWinBlocks - 1));   // ring position -> block in [wb, wb+K)
                     if (ABL & 2) owned[t] = 1u;
                     else owned[t] = (blk < numBlocks && atomicCAS(&owner[blk], 0u, me) == 0u) ? 1u : 2u;
@@ -565,6 +573,9 @@ void launch_build_own(const uint64_t* R, uint64_t n, bool packed, uint32_t strip
             case 1: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(1); break;
             case 2: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(2); break;
             case 3: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(3); break;
+            case 9: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(9); break;
+            case 17: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 17>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(17); break;
+            case 25: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 25>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(25); break;
             case 7: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(7); break;
             default: HJ_OWN_LAUNCH(0); break;
         }
