@@ -1,3 +1,5 @@
+/* Thread-scaling check of the oracle's threaded port (used to find the elided page-touch bug):
+ *   gcc -O2 -Ioracle oracle/mt_scaling_check.c oracle/hj_oracle.c -o /tmp/mt_check -lpthread -lm && /tmp/mt_check */
 #include "hj_oracle.h"
 #include <stdio.h>
 #include <stdlib.h>

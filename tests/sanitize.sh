@@ -2,7 +2,7 @@
 # CPU-side sanitizer pass (GPU ASan is not available on this pool): the oracle and the product's host-side
 # DataGen under -fsanitize=address,undefined, exercised through small C/C++ drivers.
 set -e
-cd "$(dirname "$0")/../.."
+cd "$(dirname "$0")/.."
 cat > /tmp/san_oracle.c <<'C'
 #include "hj_oracle.h"
 #include <stdio.h>

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_oracle_and_datagen_are_clean_under_asan_ubsan():
-    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "dbg", "sanitize.sh")], capture_output=True, text=True,
+    r = subprocess.run(["bash", os.path.join(ROOT, "tests", "sanitize.sh")], capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "oracle sanitizer pass ok" in r.stdout and "datagen sanitizer pass ok" in r.stdout

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """The reference's shuffle-window sweep (experiments/probe.sh, motivation.sh: local_shuffle, rSize = 2^27,
 W = 2^0 .. 2^27) on the MI355X engine: open-addressing build+probe (auto variant) and PRJ per W, one JSON line
-each, in the reference's field order plus the device timings. Optional CPU leg (the oracle's threaded port)
-every 4th W. Usage: python tools/sweep.py [--log2n 27] [--reps 3] [--cpu] > profiles/rNN_sweep.jsonl"""
+each, in the reference's field order plus the device timings. Optional CPU leg every 4th W: the product's own
+host-thread port of the reference loops (`main --algo cpu-atomic`, same flags as the reference). Usage: python tools/sweep.py [--log2n 27] [--reps 3] [--cpu] > profiles/rNN_sweep.jsonl"""
 import argparse
 import json
 import os
@@ -60,14 +60,14 @@ def main():
                                   "partition_us": pb["partition_us"], "join_us": pb["join_us"],
                                   "mtuples_per_s": 2 * n / pb["total_us"]}), flush=True)
             if a.cpu and e % 4 == 2:
-                from oracle import oracle   # baseline leg only
-                threads = min(64, os.cpu_count() or 1)
-                c = oracle.build_probe_mt(R, S, 4, 64, threads, atomic=True)
-                print(json.dumps({"algo": "atomic", "rSize": n, "probeLength": 4,
-                                  "hashBuildTimeInMicroseconds": int(c["build_us"] + c["probe_us"]), "conflicts": c["conflicts"],
-                                  "totalMatches": c["totalMatches"], "inputSum": c["inputSum"], "outputSum": c["outputSumAtomic"],
-                                  "dataDistr": "local_shuffle", "shuffleRange": W, "device": "cpu", "cpu_threads": threads,
-                                  "mtuples_per_s": 2 * n / (c["build_us"] + c["probe_us"])}), flush=True)
+                import subprocess
+                main = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "htm-hashjoin_amd", "bin", "main")
+                out = subprocess.run([main, "--algo", "cpu-atomic", "--rSize", str(n), "--probeLength", "4", "--dataDistr",
+                                      "local_shuffle", "--shuffleRange", str(W)], capture_output=True, text=True).stdout
+                c = json.loads(out)
+                c.update(dataDistr="local_shuffle", shuffleRange=W,
+                         mtuples_per_s=2 * n / max(c["hashBuildTimeInMicroseconds"], 1))
+                print(json.dumps(c), flush=True)
         ctx.dev_free(dR)
         ctx.dev_free(dS)
 
