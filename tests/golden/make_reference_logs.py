@@ -66,6 +66,14 @@ sums = sorted({(r["rSize"], r["inputSum"]) for r in rows})
 uniform_input_sums = [{"rSize": r, "inputSum": s, "dataDistr": "uniform", "shuffleRange": 16,
                        "source": "experiments/overflow_log1"} for r, s in sums]
 
+# experiments/old/uniform_log: nocc / atomic / htm on `uniform` at several sizes. Counts there are from parallel
+# (order dependent) runs; inputSum is a function of DataGen + glibc rand() only.
+rows = json_lines(os.path.join(EXP, "old", "uniform_log"))
+for r_, s_ in sorted({(r["rSize"], r["inputSum"]) for r in rows}):
+    uniform_input_sums.append({"rSize": r_, "inputSum": s_, "dataDistr": "uniform", "shuffleRange": 16,
+                               "source": "experiments/old/uniform_log"})
+uniform_parallel_conflicts = sorted({(r["algo"], r["rSize"], r["conflicts"]) for r in rows if "conflicts" in r})
+
 # experiments/motivation.sh: mc PRO "Results" (sum of bucket idx) and npo_probe: NPO match count
 mc = []
 for name, algo in (("motivation_log1", "PRO"), ("npo_probe_log1", "NPO")):
@@ -76,5 +84,6 @@ for name, algo in (("motivation_log1", "PRO"), ("npo_probe_log1", "NPO")):
     mc.append({"algo": algo, "rSize": 2 ** 27, "results": vals, "source": f"experiments/new_backup/{name}"})
 
 with open(OUT, "w") as f:
-    json.dump({"cases": cases, "uniform_input_sums": uniform_input_sums, "mc": mc}, f, indent=0)
+    json.dump({"cases": cases, "uniform_input_sums": uniform_input_sums,
+               "uniform_parallel_conflicts_not_pins": [list(t) for t in uniform_parallel_conflicts], "mc": mc}, f, indent=0)
 print(f"wrote {OUT}: {len(cases)} json cases, {len(uniform_input_sums)} uniform sums, {len(mc)} mc rows")

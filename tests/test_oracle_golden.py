@@ -88,6 +88,22 @@ def test_reference_log_pin_2p27_uniform_inputsum(golden_dir):
     assert int(R.sum(dtype=np.uint64)) == row["inputSum"]
 
 
+@pytest.mark.parametrize("log2n", [18, 20, 22, 24])
+def test_reference_log_pins_uniform_inputsum_sizes(golden_dir, log2n):
+    """experiments/old/uniform_log: inputSum of `uniform` at 2^18..2^24, for the oracle's DataGen AND the product's
+    (hj_generate_data needs no GPU). The log's conflict counts come from parallel runs and are not pins."""
+    import htm_hashjoin_amd as hj
+    rows = {r["rSize"]: r for r in _load(golden_dir, "reference_logs.json")["uniform_input_sums"]}
+    row = rows[1 << log2n]
+    R = oracle.generate_data("uniform", row["rSize"], row["rSize"], row["shuffleRange"])
+    assert int(R.sum(dtype=np.uint64)) == row["inputSum"]
+    P = hj.generate_data("uniform", row["rSize"], row["rSize"], row["shuffleRange"])
+    assert int(P.sum(dtype=np.uint64)) == row["inputSum"]
+    # the atomic rows of the same log print outputSum == inputSum: the whole-table checksum incl. dropped tuples
+    got = oracle.build_probe_seq(R, None, 4)
+    assert got["outputSumAtomic"] == row["inputSum"]
+
+
 def _pro_closed_form(n, bits=14):
     """sum over k=1..N of (k >> bits) & (nextpow2(N / 2^bits) - 1): the fork's PRO "Results"
     for unique keys 1..N (every partition holds N/2^bits tuples)."""
