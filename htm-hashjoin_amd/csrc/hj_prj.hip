@@ -24,10 +24,12 @@
 
 #include "hj_device.h"
 
+#include <cstdlib>
+#include <type_traits>
+
 namespace hj {
 
-constexpr int kTileVec = 8;                       // 16-byte loads per thread per tile
-constexpr int kTile = kBlock * kTileVec * 2;      // 4096 tuples = 32 KiB staged in LDS
+constexpr int kTile = 8192;                       // largest scatter tile (elements); chunk lengths are multiples of it
 constexpr int kMaxFan = 256;                      // <= 8 radix bits per pass
 constexpr uint32_t kJoinSlots = 32768;            // LDS table slots (uint32) = 128 KiB
 constexpr uint32_t kJoinBlockTuples = 24576;      // R tuples per LDS build (load <= 0.75)
@@ -97,11 +99,35 @@ __device__ __forceinline__ uint64_t hist_index(const PassParams& p, const ChunkR
 }
 
 // ---------------------------------------------------------------------------
+// element formats
+//   IN32 / OUT32 = false: 8-byte DataGen tuples (value = key, tuple_t{key,payload});
+//   = true: bare 32-bit keys. The join consumes keys only (bucket_chaining_join never reads
+//   the payload, :247-256 and the commented probe :264-275), so pass 1 of the PRJ path writes
+//   the key word alone and everything after it moves 4 bytes per tuple instead of 8.
+//   Inputs are read as 16-byte vectors (2 tuples or 4 keys).
+// ---------------------------------------------------------------------------
+template <bool IN32> struct Fmt { static constexpr uint32_t EPV = IN32 ? 4u : 2u; };   // elements per vector
+
+template <bool IN32, int E>
+__device__ __forceinline__ uint32_t vec_key(const uint4& t)
+{
+    if constexpr (IN32) return E == 0 ? t.x : E == 1 ? t.y : E == 2 ? t.z : t.w;
+    else return E == 0 ? t.x : t.z;
+}
+template <int E>
+__device__ __forceinline__ uint64_t vec_tuple(const uint4& t)      // 8-byte formats only
+{
+    return E == 0 ? (((uint64_t)t.y << 32) | t.x) : (((uint64_t)t.w << 32) | t.z);
+}
+
+// ---------------------------------------------------------------------------
 // histogram
 // ---------------------------------------------------------------------------
+template <bool IN32>
 __global__ void __launch_bounds__(kBlock)
-k_radix_hist(const uint64_t* __restrict__ in, PassParams p, uint32_t* __restrict__ hist)
+k_radix_hist(const void* __restrict__ in, PassParams p, uint32_t* __restrict__ hist)
 {
+    constexpr uint32_t EPV = Fmt<IN32>::EPV;
     __shared__ unsigned int h[kMaxFan];
     const uint32_t c = blockIdx.x;
     if (c >= p.chunkBase[p.nSeg]) return;
@@ -109,14 +135,17 @@ k_radix_hist(const uint64_t* __restrict__ in, PassParams p, uint32_t* __restrict
     if (threadIdx.x < kMaxFan) h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t fmask = p.fan - 1;
-    // 16-byte aligned sweep: start at the even tuple at or below begin
-    const uint32_t b0 = r.begin & ~1u;
-    const ulonglong2* in2 = reinterpret_cast<const ulonglong2*>(in);
-    for (uint32_t v = (b0 >> 1) + threadIdx.x; 2 * (uint64_t)v < r.end; v += kBlock) {
-        const ulonglong2 t = in2[v];
-        const uint32_t i = 2 * v;
-        if (i >= r.begin) atomicAdd(&h[((uint32_t)t.x >> p.shift) & fmask], 1u);
-        if (i + 1 >= r.begin && i + 1 < r.end) atomicAdd(&h[((uint32_t)t.y >> p.shift) & fmask], 1u);
+    // 16-byte aligned sweep: start at the vector that holds element `begin`
+    const uint4* in4 = reinterpret_cast<const uint4*>(in);
+    for (uint32_t v = r.begin / EPV + threadIdx.x; (uint64_t)v * EPV < r.end; v += kBlock) {
+        const uint4 t = in4[v];
+        const uint32_t i = v * EPV;
+        auto one = [&](uint32_t key, uint32_t at) {
+            if (at >= r.begin && at < r.end) atomicAdd(&h[(key >> p.shift) & fmask], 1u);
+        };
+        one(vec_key<IN32, 0>(t), i);
+        one(vec_key<IN32, 1>(t), i + 1);
+        if constexpr (IN32) { one(vec_key<IN32, 2>(t), i + 2); one(vec_key<IN32, 3>(t), i + 3); }
     }
     __syncthreads();
     if (threadIdx.x < p.fan) hist[hist_index(p, r, threadIdx.x)] = h[threadIdx.x];
@@ -128,7 +157,8 @@ k_radix_hist(const uint64_t* __restrict__ in, PassParams p, uint32_t* __restrict
 constexpr int kScanPerThread = 16;
 constexpr int kScanTile = kBlock * kScanPerThread;  // 4096
 
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* wsum /*[kBlock/64]*/, uint32_t& total)
+template <int NT = kBlock>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* wsum /*[NT/64]*/, uint32_t& total)
 {
     // inclusive scan inside the wavefront
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -142,7 +172,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
     __syncthreads();
     uint32_t wbase = 0, tot = 0;
 #pragma unroll
-    for (int k = 0; k < kBlock / 64; ++k) {
+    for (int k = 0; k < NT / 64; ++k) {
         const uint32_t s = wsum[k];
         if (k < w) wbase += s;
         tot += s;
@@ -214,103 +244,171 @@ k_seg_offsets(PassParams p, const uint32_t* __restrict__ scanned, uint32_t nTota
 
 // ---------------------------------------------------------------------------
 // scatter: tile-local counting sort in LDS, then contiguous runs to HBM
+//   NT threads, TV 16-byte loads per thread and tile -> tile = NT * TV * EPV elements.
+//   Instances: pass 1 of PRJ   tuples -> keys, 512 x 8 x 2 = 8192 per tile (128-byte runs at fan 256)
+//              pass 2 of PRJ   keys -> keys,   512 x 4 x 4 = 8192 per tile
+//              shard scatter   tuples -> (packed) tuples, 256 x 8 x 2 = 4096 per tile
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock)
-k_radix_scatter(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, PassParams p,
+template <bool IN32, bool OUT32, int NT, int TV, bool PF = true, int WPE = 1>
+__global__ void __launch_bounds__(NT, WPE)
+k_radix_scatter(const void* __restrict__ in, void* __restrict__ outv, PassParams p,
                 const uint32_t* __restrict__ scanned)
 {
-    __shared__ uint64_t stage[kTile];            // 32 KiB
-    __shared__ unsigned int tileCnt[kMaxFan];
-    __shared__ unsigned int tileOff[kMaxFan];
+    static_assert(!(IN32 && !OUT32), "keys cannot become tuples again");
+    constexpr uint32_t EPV = Fmt<IN32>::EPV;
+    constexpr int E = (int)EPV * TV;                 // elements per thread per tile
+    constexpr uint32_t TILE = (uint32_t)NT * E;
+    static_assert(!PF || E == 16, "vmcnt immediate below assumes 16 stores per thread per full tile");
+    static_assert(TILE <= 65536, "rank is kept in 16 bits");
+    using OutT = typename std::conditional<OUT32, uint32_t, uint64_t>::type;
+    OutT* __restrict__ out = static_cast<OutT*>(outv);
+
+    // Staged position q lives at stage[q + (q >> kPadShift)]: one pad element per 32 banks' worth. Without it,
+    // equal-sized bins (dense keys: every bin of a tile holds exactly TILE/fan elements) start at the same
+    // bank and lanes, whose ranks advance in step, collide (PMC: 80 % of the LDS cycles were bank conflicts).
+    constexpr uint32_t kPadShift = OUT32 ? 5 : 4;
+    constexpr uint32_t kDump = TILE + (TILE >> kPadShift);    // slot for elements outside the chunk
+    __shared__ OutT stage[kDump + 1];
+    __shared__ unsigned int tileCnt[kMaxFan];    // per bin: elements of this tile
+    __shared__ unsigned int tileOff[kMaxFan];    // exclusive scan of tileCnt
+    __shared__ unsigned int delta[kMaxFan];      // write cursor of the bin - tileOff: output index = delta[bin] + staged position
     __shared__ unsigned int cursor[kMaxFan];
-    __shared__ uint32_t wsum[kBlock / 64];
+    __shared__ unsigned int sValid;
 
     const uint32_t c = blockIdx.x;
     if (c >= p.chunkBase[p.nSeg]) return;
     const ChunkRange r = chunk_range(p, c);
     const uint32_t fmask = p.fan - 1;
-    if (threadIdx.x < p.fan) cursor[threadIdx.x] = scanned[hist_index(p, r, threadIdx.x)];
+    const uint32_t len = r.end - r.begin;
+    const bool packed = !OUT32 && p.packIdxBase != ~0ull;
+    if (threadIdx.x < kMaxFan) {
+        tileCnt[threadIdx.x] = 0;
+        cursor[threadIdx.x] = threadIdx.x < p.fan ? scanned[hist_index(p, r, threadIdx.x)] : 0;
+    }
+    __syncthreads();
 
-    const ulonglong2* in2 = reinterpret_cast<const ulonglong2*>(in);
-    const uint32_t b0 = r.begin & ~1u;
+    const uint4* in4 = reinterpret_cast<const uint4*>(in);
+    const uint32_t b0 = r.begin & ~(EPV - 1);
     // Register prefetch of the next tile (one unconditional, clamped load path; waits placed by hand: see
     // hj_build_own.hip). vmcnt counts loads and stores together in issue order: after a full tile every
-    // thread has exactly 2*kTileVec stores younger than the prefetch loads, so vmcnt(16) waits for the
-    // loads only and leaves the stores in flight.
-    static_assert(2 * kTileVec == 16, "vmcnt immediate below assumes 16 stores per thread per full tile");
-    const uint32_t lastVec = (r.end - 1) >> 1;
-    ulonglong2 nxt[kTileVec];
+    // thread has exactly E stores younger than the prefetch loads, so vmcnt(E) waits for the loads only
+    // and leaves the stores in flight.
+    const uint32_t lastVec = (r.end - 1) / EPV;
+    uint4 nxt[TV];
     auto issue = [&](uint64_t tb) {
 #pragma unroll
-        for (int k = 0; k < kTileVec; ++k) {
-            const uint64_t v = (tb >> 1) + (uint64_t)k * kBlock + threadIdx.x;
-            nxt[k] = in2[v < lastVec ? v : lastVec];
+        for (int k = 0; k < TV; ++k) {
+            const uint64_t v = tb / EPV + (uint64_t)k * NT + threadIdx.x;
+            nxt[k] = in4[v < lastVec ? v : lastVec];
         }
     };
-    issue(b0);
+    if (PF) issue(b0);
     bool prevFull = false;
-    for (uint64_t tb = b0; tb < r.end; tb += kTile) {
-        if (threadIdx.x < kMaxFan) tileCnt[threadIdx.x] = 0;
-        if (prevFull) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ulonglong2 cur[kTileVec];
+    // Three barriers per tile. The first version of this loop had eight, and a range-check branch around
+    // every LDS atomic, which made each of the 16 returning atomics of a thread its own round trip
+    // (s_waitcnt lgkmcnt(0) inside every branch): 3.6 ms per 2^30-tuple pass. Now every lane ranks every
+    // element unconditionally (one outside the chunk adds 0 and is staged to the dump slot).
+    for (uint64_t tb = b0; tb < r.end; tb += TILE) {
+        uint4 cur[TV];
+        if (PF) {
+            if (prevFull) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int k = 0; k < kTileVec; ++k) cur[k] = nxt[k];
-        __builtin_amdgcn_sched_barrier(0);
-        issue(tb + kTile);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        uint64_t tv[2 * kTileVec];
-        uint32_t br[2 * kTileVec];  // bin << 16 | rank within (tile, bin); rank < 4096
+            for (int k = 0; k < TV; ++k) cur[k] = nxt[k];
+            __builtin_amdgcn_sched_barrier(0);
+            issue(tb + TILE);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            issue(tb);
 #pragma unroll
-        for (int k = 0; k < kTileVec; ++k) {
-            const uint64_t i = tb + 2 * ((uint64_t)k * kBlock + threadIdx.x);
-            ulonglong2 t = cur[k];
-            const uint32_t binx = ((uint32_t)t.x >> p.shift) & fmask, biny = ((uint32_t)t.y >> p.shift) & fmask;
-            if (p.packIdxBase != ~0ull) {   // shard scatter: the input index travels above the (stripped) key
-                t.x = ((p.packIdxBase + i) << (32 - p.strip)) | ((uint32_t)t.x >> p.strip);
-                t.y = ((p.packIdxBase + i + 1) << (32 - p.strip)) | ((uint32_t)t.y >> p.strip);
-            }
-            tv[2 * k] = t.x; tv[2 * k + 1] = t.y;
-            br[2 * k] = br[2 * k + 1] = 0xFFFFFFFFu;
-            if (i >= r.begin && i < r.end) br[2 * k] = (binx << 16) | atomicAdd(&tileCnt[binx], 1u);
-            if (i + 1 >= r.begin && i + 1 < r.end) br[2 * k + 1] = (biny << 16) | atomicAdd(&tileCnt[biny], 1u);
+            for (int k = 0; k < TV; ++k) cur[k] = nxt[k];
         }
-        __syncthreads();
-        {   // exclusive scan of tileCnt[0..fan) (fan <= 256 = one value per thread)
-            const uint32_t v = threadIdx.x < p.fan ? tileCnt[threadIdx.x] : 0;
-            uint32_t total;
-            const uint32_t ex = block_exclusive_scan(v, wsum, total);
-            if (threadIdx.x < kMaxFan) tileOff[threadIdx.x] = ex;
-        }
-        __syncthreads();
+        // ---- rank: position of every element inside its (tile, bin) ----
+        OutT tv[E];
+        uint32_t br[E];      // bin << 16 | rank
+        uint32_t okMask = 0;
+        // offset from the chunk's first element; wraps below zero (= huge) for the elements before `begin`
+        const uint32_t rel0 = (uint32_t)tb - r.begin + EPV * threadIdx.x;
+        auto one = [&](int slot, uint32_t key, uint64_t tuple, uint32_t rel) {
+            const uint32_t bin = (key >> p.shift) & fmask;
+            const bool ok = rel < len;
+            if constexpr (OUT32) tv[slot] = key;
+            else tv[slot] = packed           // shard scatter: the input index travels above the (stripped) key
+                                ? (((p.packIdxBase + r.begin + rel) << (32 - p.strip)) | (key >> p.strip)) : tuple;
+            okMask |= ok ? (1u << slot) : 0u;
+            br[slot] = (bin << 16) | atomicAdd(&tileCnt[bin], ok ? 1u : 0u);
+        };
 #pragma unroll
-        for (int k = 0; k < 2 * kTileVec; ++k)
-            if (br[k] != 0xFFFFFFFFu) stage[tileOff[br[k] >> 16] + (br[k] & 0xFFFFu)] = tv[k];
-        __syncthreads();
-        const uint32_t valid = tileOff[p.fan - 1] + tileCnt[p.fan - 1];
-#pragma unroll
-        for (int k = 0; k < 2 * kTileVec; ++k) {
-            const uint32_t q = (uint32_t)k * kBlock + threadIdx.x;
-            if (q < valid) {
-                const uint64_t t = stage[q];
-                // bin of staged position q: packed tuples no longer carry their bin bits, so look it up
-                // (largest bin with tileOff[bin] <= q; fan <= 256 -> 8 steps of binary search in LDS)
-                uint32_t bin;
-                if (p.packIdxBase == ~0ull) {
-                    bin = ((uint32_t)t >> p.shift) & fmask;
-                } else {
-                    uint32_t lo = 0, hi = p.fan;
-                    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tileOff[mid] <= q) lo = mid; else hi = mid; }
-                    bin = lo;
-                }
-                out[cursor[bin] + (q - tileOff[bin])] = t;
+        for (int k = 0; k < TV; ++k) {
+            const uint32_t rel = rel0 + EPV * (uint32_t)k * NT;
+            const uint4 t = cur[k];
+            if constexpr (IN32) {
+                one(4 * k, t.x, 0, rel); one(4 * k + 1, t.y, 0, rel + 1); one(4 * k + 2, t.z, 0, rel + 2); one(4 * k + 3, t.w, 0, rel + 3);
+            } else {
+                one(2 * k, t.x, vec_tuple<0>(t), rel); one(2 * k + 1, t.z, vec_tuple<1>(t), rel + 1);
             }
         }
         __syncthreads();
-        if (threadIdx.x < p.fan) cursor[threadIdx.x] += tileCnt[threadIdx.x];
-        prevFull = (valid == (uint32_t)kTile);
-        // (next iteration's first barrier orders the cursor update)
+        // ---- one wavefront: exclusive scan of the 256 counters (4 per lane), cursors, reset ----
+        if (threadIdx.x < 64) {
+            const uint32_t b4 = 4 * threadIdx.x;
+            uint32_t cnt[4], sum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { cnt[j] = tileCnt[b4 + j]; tileCnt[b4 + j] = 0; sum += cnt[j]; }
+            uint32_t inc = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t n = __shfl_up(inc, off, 64);
+                if ((int)threadIdx.x >= off) inc += n;
+            }
+            uint32_t ex = inc - sum;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t cu = cursor[b4 + j];
+                tileOff[b4 + j] = ex;
+                delta[b4 + j] = cu - ex;
+                cursor[b4 + j] = cu + cnt[j];
+                ex += cnt[j];
+            }
+            if (threadIdx.x == 63) sValid = inc;
+        }
+        __syncthreads();
+        // ---- stage: tile-local counting sort ----
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            const uint32_t at = tileOff[br[k] >> 16] + (br[k] & 0xFFFFu);
+            stage[((okMask >> k) & 1u) ? at + (at >> kPadShift) : kDump] = tv[k];
+        }
+        __syncthreads();
+        // ---- contiguous runs to HBM ----
+        const uint32_t valid = sValid;
+        auto emit = [&](uint32_t q) {
+            const OutT t = stage[q + (q >> kPadShift)];
+            // bin of staged position q: packed tuples no longer carry their bin bits, so look it up
+            // (largest bin with tileOff[bin] <= q; fan <= 256 -> 8 steps of binary search in LDS)
+            uint32_t bin;
+            if (!packed) {
+                bin = ((uint32_t)t >> p.shift) & fmask;
+            } else {
+                uint32_t lo = 0, hi = p.fan;
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tileOff[mid] <= q) lo = mid; else hi = mid; }
+                bin = lo;
+            }
+            out[delta[bin] + q] = t;
+        };
+        if (valid == TILE) {
+#pragma unroll
+            for (int k = 0; k < E; ++k) emit((uint32_t)k * NT + threadIdx.x);
+        } else {
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                const uint32_t q = (uint32_t)k * NT + threadIdx.x;
+                if (q < valid) emit(q);
+            }
+        }
+        prevFull = (valid == TILE);
+        // (the next tile's atomics touch only tileCnt, reset above; its scan step, which rewrites
+        //  tileOff/delta, runs after a barrier every wavefront reaches only when it has finished this phase)
     }
 }
 
@@ -344,8 +442,8 @@ constexpr int kJoinPre = 16;   // tuples per thread and relation prefetched in r
 // one unconditional clamped load path -- see hj_build_own.hip for why). Measured at 2^30: 13.4 ms -> see
 // profiles/.
 __global__ void __launch_bounds__(kJoinThreads)
-k_prj_join(const uint64_t* __restrict__ partR, const uint32_t* __restrict__ offR,
-           const uint64_t* __restrict__ partS, const uint32_t* __restrict__ offS,
+k_prj_join(const uint32_t* __restrict__ partR, const uint32_t* __restrict__ offR,
+           const uint32_t* __restrict__ partS, const uint32_t* __restrict__ offS,
            uint32_t radixBits, uint32_t nParts, uint32_t nRtotal, uint32_t nStotal, Counters* __restrict__ ctr)
 {
     extern __shared__ uint32_t tab[];  // kJoinSlots
@@ -355,7 +453,7 @@ k_prj_join(const uint64_t* __restrict__ partR, const uint32_t* __restrict__ offR
 
     // Register pipeline: S(p) is loaded while R(p) is built, R(p+1) while S(p) is probed; each buffer is
     // refilled only after its last use, so no copy of in-flight registers is ever needed.
-    uint64_t bufR[kJoinPre], bufS[kJoinPre];
+    uint32_t bufR[kJoinPre], bufS[kJoinPre];   // partitions hold bare keys (see element formats above)
     auto load_R = [&](uint32_t pid) {   // clamped: every lane always loads a valid address; validity decided at use
         const uint32_t rb0 = offR[pid < nParts ? pid : nParts - 1];
 #pragma unroll
@@ -398,14 +496,14 @@ k_prj_join(const uint64_t* __restrict__ partR, const uint32_t* __restrict__ offR
 #pragma unroll
             for (int j = 0; j < kJoinPre; ++j) {
                 if (j * kJoinThreads + threadIdx.x < nR) {
-                    const uint32_t k = (uint32_t)bufR[j] >> radixBits;   // distinguishes keys inside a partition
+                    const uint32_t k = bufR[j] >> radixBits;   // distinguishes keys inside a partition
                     checksum += k & idxMask;                          // :249,256
                     uint32_t h = join_hash(k);
                     while (atomicCAS(&tab[h], kEmpty32, k) != kEmpty32) h = (h + 1) & (kJoinSlots - 1);
                 }
             }
             for (uint32_t i = rb + kJoinPre * kJoinThreads + threadIdx.x; i < re; i += kJoinThreads) {   // tuples 16384..
-                const uint32_t k = (uint32_t)partR[i] >> radixBits;
+                const uint32_t k = partR[i] >> radixBits;
                 checksum += k & idxMask;
                 uint32_t h = join_hash(k);
                 while (atomicCAS(&tab[h], kEmpty32, k) != kEmpty32) h = (h + 1) & (kJoinSlots - 1);
@@ -418,7 +516,7 @@ k_prj_join(const uint64_t* __restrict__ partR, const uint32_t* __restrict__ offR
 #pragma unroll
             for (int j = 0; j < kJoinPre; ++j) {
                 if (j * kJoinThreads + threadIdx.x < nS) {
-                    const uint32_t k = (uint32_t)bufS[j] >> radixBits;
+                    const uint32_t k = bufS[j] >> radixBits;
                     uint32_t h = join_hash(k);
                     for (;;) {
                         const uint32_t v = tab[h];
@@ -429,7 +527,7 @@ k_prj_join(const uint64_t* __restrict__ partR, const uint32_t* __restrict__ offR
                 }
             }
             for (uint32_t i = sb + kJoinPre * kJoinThreads + threadIdx.x; i < se; i += kJoinThreads) {
-                const uint32_t k = (uint32_t)partS[i] >> radixBits;
+                const uint32_t k = partS[i] >> radixBits;
                 uint32_t h = join_hash(k);
                 for (;;) {
                     const uint32_t v = tab[h];
@@ -449,14 +547,14 @@ k_prj_join(const uint64_t* __restrict__ partR, const uint32_t* __restrict__ offR
                 for (uint32_t i = threadIdx.x; i < kJoinSlots; i += kJoinThreads) tab[i] = kEmpty32;
                 __syncthreads();
                 for (uint32_t i = blk + threadIdx.x; i < bend; i += kJoinThreads) {
-                    const uint32_t k = (uint32_t)partR[i] >> radixBits;
+                    const uint32_t k = partR[i] >> radixBits;
                     checksum += k & idxMask;
                     uint32_t h = join_hash(k);
                     while (atomicCAS(&tab[h], kEmpty32, k) != kEmpty32) h = (h + 1) & (kJoinSlots - 1);
                 }
                 __syncthreads();
                 for (uint32_t i = sb + threadIdx.x; i < se; i += kJoinThreads) {
-                    const uint32_t k = (uint32_t)partS[i] >> radixBits;
+                    const uint32_t k = partS[i] >> radixBits;
                     uint32_t h = join_hash(k);
                     for (;;) {
                         const uint32_t v = tab[h];
@@ -559,7 +657,8 @@ Work carve(const PrjPlan& pl, void* base, uint64_t n)
 }
 
 // One radix pass: in -> out, segments segIn[nSeg+1] -> segOut[nSeg*fan+1].
-void run_pass(const uint64_t* in, uint64_t* out, uint64_t n, const uint32_t* segIn, uint32_t nSeg,
+// in32: the input already holds bare keys (pass 2); the output always does.
+void run_pass(const void* in, bool in32, uint32_t* out, uint64_t n, const uint32_t* segIn, uint32_t nSeg,
               uint32_t shift, uint32_t bits, uint32_t* segOut, const Work& w, hipStream_t s)
 {
     const uint32_t fan = 1u << bits;
@@ -568,24 +667,31 @@ void run_pass(const uint64_t* in, uint64_t* out, uint64_t n, const uint32_t* seg
     PassParams p{segIn, nSeg, l.chunkLen, w.chunkBase, shift, fan, ~0ull, 0u};
     // entries past the live chunks must be zero for the scan to be a prefix of live data only
     hipMemsetAsync(w.hist, 0, sizeof(uint32_t) * l.histEntries, s);
-    hipLaunchKernelGGL(k_radix_hist, dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s, in, p, w.hist);
+    if (in32) hipLaunchKernelGGL(k_radix_hist<true>, dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s, in, p, w.hist);
+    else hipLaunchKernelGGL(k_radix_hist<false>, dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s, in, p, w.hist);
     hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)l.scanBlocks), dim3(kBlock), 0, s, w.hist, l.histEntries, w.sums);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, s, w.sums, (uint32_t)l.scanBlocks);
     hipLaunchKernelGGL(k_scan_add, dim3((unsigned)l.scanBlocks), dim3(kBlock), 0, s, w.hist, l.histEntries, w.sums);
     const uint32_t nOut = nSeg * fan + 1;
     hipLaunchKernelGGL(k_seg_offsets, dim3((nOut + kBlock - 1) / kBlock), dim3(kBlock), 0, s, p, w.hist, (uint32_t)n, segOut);
-    hipLaunchKernelGGL(k_radix_scatter, dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s, in, out, p, w.hist);
+    // instance choice measured at 2^30 (tools/prj_variants.sh, profiles/r01_prj_variants.txt): 512 threads x 16
+    // elements, no register prefetch, <= 128 VGPRs (2 workgroups per CU); more, smaller workgroups and the
+    // prefetching instance were slower or equal
+    if (in32) hipLaunchKernelGGL((k_radix_scatter<true, true, 512, 4, false, 4>), dim3((unsigned)l.maxChunks), dim3(512), 0, s,
+                                 in, static_cast<void*>(out), p, w.hist);
+    else hipLaunchKernelGGL((k_radix_scatter<false, true, 512, 8, false, 4>), dim3((unsigned)l.maxChunks), dim3(512), 0, s,
+                            in, static_cast<void*>(out), p, w.hist);
 }
 
 void partition_relation(const PrjPlan& pl, const Work& w, const uint64_t* in, uint64_t n,
-                        uint64_t* tmp, uint64_t* out, uint32_t* finalOff, hipStream_t s)
+                        uint32_t* tmp, uint32_t* out, uint32_t* finalOff, hipStream_t s)
 {
     hipLaunchKernelGGL(k_init_seg, dim3(1), dim3(64), 0, s, w.seg0, (uint32_t)n);
     if (pl.bits2 == 0) {
-        run_pass(in, out, n, w.seg0, 1, 0, pl.bits1, finalOff, w, s);
+        run_pass(in, false, out, n, w.seg0, 1, 0, pl.bits1, finalOff, w, s);
     } else {
-        run_pass(in, tmp, n, w.seg0, 1, 0, pl.bits1, w.seg1, w, s);                          // pass 1, R = 0
-        run_pass(tmp, out, n, w.seg1, 1u << pl.bits1, pl.bits1, pl.bits2, finalOff, w, s);    // pass 2, R = bits1
+        run_pass(in, false, tmp, n, w.seg0, 1, 0, pl.bits1, w.seg1, w, s);                         // pass 1, R = 0: tuples -> keys
+        run_pass(tmp, true, out, n, w.seg1, 1u << pl.bits1, pl.bits1, pl.bits2, finalOff, w, s);    // pass 2, R = bits1
     }
 }
 }  // namespace
@@ -595,8 +701,11 @@ void launch_prj(const PrjPlan& pl, const PrjBuffers& buf, const uint64_t* R, uin
 {
     const uint64_t n = nR > nS ? nR : nS;
     const Work w = carve(pl, buf.work, n);
-    partition_relation(pl, w, R, nR, buf.tmpA, buf.partR, w.offR, s);
-    if (S) partition_relation(pl, w, S, nS, buf.tmpA, buf.partS, w.offS, s);
+    uint32_t* const tmp = reinterpret_cast<uint32_t*>(buf.tmpA);
+    uint32_t* const partR = reinterpret_cast<uint32_t*>(buf.partR);
+    uint32_t* const partS = reinterpret_cast<uint32_t*>(buf.partS);
+    partition_relation(pl, w, R, nR, tmp, partR, w.offR, s);
+    if (S) partition_relation(pl, w, S, nS, tmp, partS, w.offS, s);
     if (evPartDone) hipEventRecord(evPartDone, s);
     const uint32_t P = 1u << pl.radixBits;
     static bool attrSet = false;
@@ -613,7 +722,7 @@ void launch_prj(const PrjPlan& pl, const PrjBuffers& buf, const uint64_t* R, uin
     }
     const unsigned grid = P < (uint32_t)nCU ? P : (unsigned)nCU;   // one persistent workgroup per CU
     hipLaunchKernelGGL(k_prj_join, dim3(grid), dim3(kJoinThreads), kJoinSlots * sizeof(uint32_t), s,
-                       buf.partR, w.offR, S ? buf.partS : nullptr, w.offS, pl.radixBits, P, (uint32_t)nR,
+                       (const uint32_t*)partR, w.offR, S ? (const uint32_t*)partS : nullptr, w.offS, pl.radixBits, P, (uint32_t)nR,
                        (uint32_t)(S ? nS : 1), ctr);
 }
 
@@ -659,7 +768,7 @@ void launch_shard_hist(const uint64_t* in, uint64_t n, uint32_t nShards, void* w
     hipLaunchKernelGGL(k_chunk_base, dim3(1), dim3(64), 0, s, w.seg0, 1u, l.chunkLen, w.chunkBase);
     PassParams p{w.seg0, 1u, l.chunkLen, w.chunkBase, 0u, nShards, ~0ull, 0u};
     (void)hipMemsetAsync(w.hist, 0, sizeof(uint32_t) * l.histEntries, s);
-    hipLaunchKernelGGL(k_radix_hist, dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s, in, p, w.hist);
+    hipLaunchKernelGGL(k_radix_hist<false>, dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s, static_cast<const void*>(in), p, w.hist);
     hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)l.scanBlocks), dim3(kBlock), 0, s, w.hist, l.histEntries, w.sums);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, s, w.sums, (uint32_t)l.scanBlocks);
     hipLaunchKernelGGL(k_scan_add, dim3((unsigned)l.scanBlocks), dim3(kBlock), 0, s, w.hist, l.histEntries, w.sums);
@@ -673,7 +782,8 @@ void launch_shard_scatter_ordered(const uint64_t* in, uint64_t n, uint32_t nShar
     const ShardWork w = shard_carve(work, n, nShards);
     const PassLayout l = pass_layout(n, 1, nShards);
     PassParams p{w.seg0, 1u, l.chunkLen, w.chunkBase, 0u, nShards, packIdxBase, strip};
-    hipLaunchKernelGGL(k_radix_scatter, dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s, in, out, p, w.hist);
+    hipLaunchKernelGGL((k_radix_scatter<false, false, kBlock, 8>), dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s,
+                       static_cast<const void*>(in), static_cast<void*>(out), p, w.hist);
 }
 
 }  // namespace hj
