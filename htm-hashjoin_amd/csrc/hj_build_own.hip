@@ -99,7 +99,7 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
             unsigned int* __restrict__ owner, DeferredEntry* __restrict__ queue,
             unsigned long long* __restrict__ queueCount, Counters* __restrict__ ctr)
 {
-    extern __shared__ uint64_t win[];            // kWinSlots slots, ring indexed by (slot & (kWinSlots-1))
+    extern __shared__ __align__(16) uint64_t win[];   // kWinSlots slots, ring indexed by (slot & (kWinSlots-1))
     __shared__ unsigned int owned[kWinBlocks];   // per ring block: 0 = not tried yet, 1 = claimed by this workgroup, 2 = someone else's
     __shared__ unsigned int need[kWinBlocks];    // per ring block: wanted by the current tile (count, or 0x10000 = unconditional)
     __shared__ unsigned int sTileMin;
@@ -573,6 +573,7 @@ void launch_build_own(const uint64_t* R, uint64_t n, bool packed, uint32_t strip
             case 1: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(1); break;
             case 2: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(2); break;
             case 3: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(3); break;
+            case 5: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(5); break;
             case 9: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(9); break;
             case 17: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 17>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(17); break;
             case 25: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 25>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(25); break;
