@@ -19,8 +19,10 @@ HJ_ERR_KEY_RANGE = -5
 HJ_ERR_UNKNOWN_ALGO = -6
 HJ_ERR_STATE = -7
 
-HJ_ALGO_NOCC, HJ_ALGO_ATOMIC, HJ_ALGO_HTM, HJ_ALGO_PRJ = 0, 1, 2, 3
-ALGO_IDS = {"nocc": HJ_ALGO_NOCC, "atomic": HJ_ALGO_ATOMIC, "htm": HJ_ALGO_HTM, "prj": HJ_ALGO_PRJ}
+HJ_ALGO_NOCC, HJ_ALGO_ATOMIC, HJ_ALGO_HTM, HJ_ALGO_PRJ, HJ_ALGO_AUTO = 0, 1, 2, 3, 4
+ALGO_IDS = {"nocc": HJ_ALGO_NOCC, "atomic": HJ_ALGO_ATOMIC, "htm": HJ_ALGO_HTM, "prj": HJ_ALGO_PRJ,
+            "auto": HJ_ALGO_AUTO}
+ALGO_NAMES = {v: k for k, v in ALGO_IDS.items()}
 
 
 class hj_params(C.Structure):
@@ -45,11 +47,14 @@ class hj_result(C.Structure):
         + [("radixBits", C.c_uint32), ("buildVariant", C.c_uint32)]
         + [(n, C.c_double) for n in (
             "clear_us", "build_us", "probe_us", "partition_us", "join_us", "total_us", "h2d_us")]
-        + [("buildDeferred", C.c_uint64), ("buildPhaseA_us", C.c_double), ("reserved", C.c_uint64 * 2)]
+        + [("buildDeferred", C.c_uint64), ("buildPhaseA_us", C.c_double), ("algoUsed", C.c_uint32),
+           ("reserved0", C.c_uint32), ("reserved", C.c_uint64 * 1)]
     )
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+        d = {n: getattr(self, n) for n, _ in self._fields_ if not n.startswith("reserved")}
+        d["algoUsed"] = ALGO_NAMES.get(d["algoUsed"], d["algoUsed"])
+        return d
 
 
 def _declare(lib):
@@ -69,6 +74,7 @@ def _declare(lib):
         "hj_build_dev": ([vp, vp, u64, u64], i32),
         "hj_probe_dev": ([vp, vp, u64], i32),
         "hj_prj_join_dev": ([vp, vp, u64, vp, u64], i32),
+        "hj_join_dev": ([vp, vp, u64, vp, u64], i32),
         "hj_checksums_dev": ([vp], i32),
         "hj_fetch_result": ([vp, P(hj_result)], i32),
         "hj_export_table": ([vp, vp, u64], i32),

@@ -45,6 +45,8 @@ struct hj_ctx {
     uint64_t *tmpA = nullptr, *partR = nullptr, *partS = nullptr;
     void* work = nullptr;
     uint64_t capTmp = 0, capPartR = 0, capPartS = 0;
+    uint32_t forceVariant = 0;                  // hj_join_dev(AUTO) has already sampled: build with this variant
+    uint32_t algoUsed = 0;
     size_t capWork = 0;
     bool prjRan = false;
     // staging for hj_run
@@ -216,11 +218,11 @@ int hj_synchronize(hj_ctx* c)
 int hj_reserve(hj_ctx* c, const hj_params* params, uint64_t rSize, uint64_t sSize)
 {
     if (!c || !params) return HJ_ERR_INVALID;
-    if (params->algo > HJ_ALGO_PRJ) return fail(c, HJ_ERR_UNKNOWN_ALGO, "hj_reserve: algo");
+    if (params->algo > HJ_ALGO_AUTO) return fail(c, HJ_ERR_UNKNOWN_ALGO, "hj_reserve: algo");
     if (rSize == 0) return fail(c, HJ_ERR_INVALID, "hj_reserve: rSize == 0");
     HJ_HIP(c, hipSetDevice(c->device));
     c->params = *params;
-    if (params->algo == HJ_ALGO_PRJ) {
+    if (params->algo == HJ_ALGO_PRJ || params->algo == HJ_ALGO_AUTO) {
         if (rSize >= 0xFFFFFFFFull || sSize >= 0xFFFFFFFFull)
             return fail(c, HJ_ERR_INVALID, "hj_reserve: PRJ sizes must be < 2^32 tuples per device");
         uint32_t bits = params->radixBits ? params->radixBits : auto_radix_bits(rSize);
@@ -237,7 +239,7 @@ int hj_reserve(hj_ctx* c, const hj_params* params, uint64_t rSize, uint64_t sSiz
             HJ_HIP(c, hipMalloc(&c->work, c->plan.workspaceBytes));
             c->capWork = c->plan.workspaceBytes;
         }
-        return HJ_OK;
+        if (params->algo == HJ_ALGO_PRJ) return HJ_OK;      // AUTO also needs the open-addressing buffers below
     }
     if (!is_pow2(rSize)) return fail(c, HJ_ERR_INVALID, "hj_reserve: rSize must be a power of two (DataGen.hpp:28, NoCCHashBuild.hpp:36)");
     if (rSize > (1ull << 31)) return fail(c, HJ_ERR_INVALID, "hj_reserve: rSize > 2^31 per device");
@@ -259,6 +261,19 @@ int hj_reserve(hj_ctx* c, const hj_params* params, uint64_t rSize, uint64_t sSiz
     return HJ_OK;
 }
 
+// Locality pre-round: 256 sample tiles; the LDS-window kernel is worth taking if it would have to defer at
+// most 1/12 of the tuples (measured at 2^27, local_shuffle: W=2^11 defers 3.8 % and runs 2.1 ms against
+// 5.7 ms for the global-atomic kernel; W=2^12 defers 36 % and runs 12.9 ms against 5.8).
+static int sample_is_local(hj_ctx* c, const uint64_t* d, uint64_t n, uint64_t tableSize, uint32_t strip, bool* local)
+{
+    const uint32_t nSample = 256;
+    launch_sample_locality(d, n, tableSize, strip, nSample, c->fitCount, c->stream);
+    HJ_HIP(c, hipMemcpyAsync(c->hFit, c->fitCount, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+    HJ_HIP(c, hipStreamSynchronize(c->stream));
+    *local = (uint64_t)c->hFit[0] * 12 <= (uint64_t)c->hFit[1];
+    return HJ_OK;
+}
+
 // Shared by hj_build_dev (DataGen tuples) and hj_build_packed_dev (index-packed tuples).
 static int build_common(hj_ctx* c, const uint64_t* d, uint64_t n, bool packed, uint32_t strip, uint32_t shard,
                         uint64_t tableSize, uint64_t idxBase)
@@ -271,24 +286,20 @@ static int build_common(hj_ctx* c, const uint64_t* d, uint64_t n, bool packed, u
     int rc;
     if ((rc = record(c, EV_CLEAR0))) return rc;
     // which build kernel: 2 needs its buffers (hj_reserve) and a table of at least one window
-    uint32_t variant = c->params.buildVariant;
+    uint32_t variant = c->forceVariant ? c->forceVariant : c->params.buildVariant;
     const bool canOwn = own_supported(tableSize) && c->capOwner >= own_owner_bytes(tableSize) &&
                         c->capQueue >= own_queue_bytes(n);
     if (variant == 2 && !canOwn) variant = 1;
     if (variant == 0) {
         variant = 1;
         if (canOwn && n) {
-            // locality pre-round: 256 sample tiles; take the LDS-window kernel if it would have to defer at
-            // most 1/12 of the tuples (measured at 2^27, local_shuffle: W=2^11 defers 3.8 % and runs 2.1 ms
-            // against 5.7 ms for the global-atomic kernel; W=2^12 defers 36 % and runs 12.9 ms against 5.8)
-            const uint32_t nSample = 256;
-            launch_sample_locality(d, n, tableSize, strip, nSample, c->fitCount, c->stream);
-            HJ_HIP(c, hipMemcpyAsync(c->hFit, c->fitCount, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
-            HJ_HIP(c, hipStreamSynchronize(c->stream));
-            if ((uint64_t)c->hFit[0] * 12 <= (uint64_t)c->hFit[1]) variant = 2;
+            bool local = false;
+            if ((rc = sample_is_local(c, d, n, tableSize, strip, &local))) return rc;
+            if (local) variant = 2;
         }
     }
     c->variantUsed = variant;
+    c->algoUsed = c->params.algo == HJ_ALGO_AUTO ? (uint32_t)HJ_ALGO_ATOMIC : c->params.algo;
     if (variant == 2) {
         if ((rc = record(c, EV_BUILD0))) return rc;
         launch_build_own(d, n, packed, strip, shard, c->table, tableSize, probe_len(c->params), idxBase, c->ownerBuf,
@@ -346,7 +357,8 @@ int hj_probe_dev(hj_ctx* c, const uint64_t* dS, uint64_t sSize)
 int hj_prj_join_dev(hj_ctx* c, const uint64_t* dR, uint64_t rSize, const uint64_t* dS, uint64_t sSize)
 {
     if (!c || !dR || rSize == 0) return HJ_ERR_INVALID;
-    if (c->params.algo != HJ_ALGO_PRJ) return fail(c, HJ_ERR_STATE, "hj_prj_join_dev: context not reserved for PRJ");
+    if (c->params.algo != HJ_ALGO_PRJ && c->params.algo != HJ_ALGO_AUTO)
+        return fail(c, HJ_ERR_STATE, "hj_prj_join_dev: context not reserved for PRJ");
     const uint64_t nmax = rSize > sSize ? rSize : sSize;
     if (nmax + 2 > c->capTmp || rSize + 2 > c->capPartR || (dS && sSize + 2 > c->capPartS))
         return fail(c, HJ_ERR_STATE, "hj_prj_join_dev: hj_reserve() not called for these sizes");
@@ -366,7 +378,37 @@ int hj_prj_join_dev(hj_ctx* c, const uint64_t* dR, uint64_t rSize, const uint64_
     if ((rc = record(c, EV_PRJ1))) return rc;
     HJ_HIP(c, hipGetLastError());
     c->prjRan = true;
+    c->algoUsed = HJ_ALGO_PRJ;
     return HJ_OK;
+}
+
+int hj_join_dev(hj_ctx* c, const uint64_t* dR, uint64_t rSize, const uint64_t* dS, uint64_t sSize)
+{
+    if (!c || !dR || rSize == 0) return HJ_ERR_INVALID;
+    if (!dS) sSize = 0;
+    int rc;
+    bool prj = c->params.algo == HJ_ALGO_PRJ;
+    uint32_t force = 0;
+    if (c->params.algo == HJ_ALGO_AUTO) {
+        // the same question the build asks itself for buildVariant 0, asked once here: with locality the
+        // LDS-window build + linear probe wins, without it both of them turn into random HBM accesses
+        // and two radix passes are cheaper
+        if (!is_pow2(rSize) || 2 * rSize + kTableSlack > c->tableCapSlots)
+            return fail(c, HJ_ERR_STATE, "hj_join_dev: hj_reserve() not called for this rSize");
+        HJ_HIP(c, hipSetDevice(c->device));
+        bool local = false;
+        const bool canOwn = own_supported(2 * rSize) && c->capOwner >= own_owner_bytes(2 * rSize) &&
+                            c->capQueue >= own_queue_bytes(rSize);
+        if (canOwn && c->params.buildVariant != 1 && (rc = sample_is_local(c, dR, rSize, 2 * rSize, 0, &local))) return rc;
+        prj = !local;
+        force = 2;
+    }
+    if (prj) return hj_prj_join_dev(c, dR, rSize, dS, sSize);
+    c->forceVariant = force;
+    rc = hj_build_dev(c, dR, rSize, 0);
+    c->forceVariant = 0;
+    if (rc) return rc;
+    return hj_probe_dev(c, dS, sSize);
 }
 
 int hj_checksums_dev(hj_ctx* c)
@@ -417,6 +459,7 @@ int hj_fetch_result(hj_ctx* c, hj_result* out)
         out->total_us = out->build_us + out->probe_us;
     }
     out->h2d_us = c->h2d_us;
+    out->algoUsed = c->algoUsed;
     if (k.badKeys) return fail(c, HJ_ERR_KEY_RANGE, "input holds tuples with payload bits set or value 0");
     return HJ_OK;
 }
@@ -452,13 +495,8 @@ int hj_run(hj_ctx* c, const hj_params* params, const uint64_t* relR, uint64_t rS
     if (sSize) HJ_HIP(c, hipMemcpyAsync(c->stageS, relS, sSize * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     HJ_HIP(c, hipStreamSynchronize(c->stream));
     c->h2d_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-    if (params->algo == HJ_ALGO_PRJ) {
-        if ((rc = hj_prj_join_dev(c, c->stageR, rSize, sSize ? c->stageS : nullptr, sSize))) return rc;
-    } else {
-        if ((rc = hj_build_dev(c, c->stageR, rSize, 0))) return rc;
-        if (sSize && (rc = hj_probe_dev(c, c->stageS, sSize))) return rc;
-        if ((rc = hj_checksums_dev(c))) return rc;
-    }
+    if ((rc = hj_join_dev(c, c->stageR, rSize, sSize ? c->stageS : nullptr, sSize))) return rc;
+    if (!c->prjRan && (rc = hj_checksums_dev(c))) return rc;
     return hj_fetch_result(c, out);
 }
 

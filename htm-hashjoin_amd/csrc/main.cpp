@@ -9,6 +9,9 @@
 //   atomic | htm | hip-atomic   open-addressing build+probe on the GPU (the TSX /
 //                               CAS insert loops replaced by the index-priority kernels)
 //   prj | hip-prj | PRO         radix-partitioned join on the GPU
+//   auto                        samples R for locality and runs one of the two above
+//                               (the reference's adaptive idea, HTMHashBuild.hpp:98-154);
+//                               "algoUsed" in the JSON line says which
 //   nocc | cpu-atomic           the reference's own loops on host threads
 //                               (NoCCHashBuild.hpp:37-81 / AtomicHashBuild.hpp:37-86):
 //                               the plumbing / CPU-baseline path; never a fallback --
@@ -159,9 +162,10 @@ int main(int argc, char* argv[])
     parseArgs(argc, argv, &p);
 
     const bool gpuOA = p.algo == "atomic" || p.algo == "htm" || p.algo == "hip-atomic";
-    const bool gpuPRJ = p.algo == "prj" || p.algo == "hip-prj" || p.algo == "PRO";
+    bool gpuPRJ = p.algo == "prj" || p.algo == "hip-prj" || p.algo == "PRO";
+    const bool gpuAuto = p.algo == "auto";
     const bool cpu = p.algo == "nocc" || p.algo == "cpu-atomic";
-    if (!gpuOA && !gpuPRJ && !cpu) {
+    if (!gpuOA && !gpuPRJ && !gpuAuto && !cpu) {
         std::cout << "Unknown Algo: " << p.algo << std::endl;  // main.cpp:108
         return 0;
     }
@@ -205,7 +209,7 @@ int main(int argc, char* argv[])
             return 2;
         }
         hj_params hp{};
-        hp.algo = gpuPRJ ? HJ_ALGO_PRJ : (p.algo == "htm" ? HJ_ALGO_HTM : HJ_ALGO_ATOMIC);
+        hp.algo = gpuAuto ? HJ_ALGO_AUTO : gpuPRJ ? HJ_ALGO_PRJ : (p.algo == "htm" ? HJ_ALGO_HTM : HJ_ALGO_ATOMIC);
         hp.scaleOutput = p.scaleOutput; hp.numPartitions = p.numPartitions; hp.probeLength = p.probeLength;
         hp.transactionSize = p.transactionSize; hp.radixBits = p.radixBits;
         hj_result r{};
@@ -215,6 +219,7 @@ int main(int argc, char* argv[])
             hj_destroy(ctx);
             return 2;
         }
+        if (gpuAuto) gpuPRJ = r.algoUsed == HJ_ALGO_PRJ;     // print the fields of the path that ran
         const double mt = (double)(p.rSize + (S ? sSize : 0)) / r.total_us;
         std::cout << "{\"algo\": \"" << p.algo << "\",\"rSize\": " << p.rSize;
         if (p.algo == "htm") std::cout << ", \"transactionSize\": " << p.transactionSize;
@@ -223,6 +228,7 @@ int main(int argc, char* argv[])
         if (p.probe) std::cout << ", \"totalMatches\": " << r.totalMatches;
         if (gpuPRJ) std::cout << ", \"results\": " << r.prjChecksum << ", \"radixBits\": " << r.radixBits;
         else std::cout << ", \"inputSum\": " << r.inputSum << ", \"outputSum\": " << r.outputSum;
+        if (gpuAuto) std::cout << ", \"algoUsed\": \"" << (gpuPRJ ? "prj" : "atomic") << "\"";
         std::cout << ", \"device\": \"hip\", \"sSize\": " << (S ? sSize : 0) << ", \"mtuples_per_s\": " << mt
                   << ", \"clear_us\": " << r.clear_us << ", \"build_us\": " << r.build_us << ", \"probe_us\": " << r.probe_us
                   << ", \"partition_us\": " << r.partition_us << ", \"join_us\": " << r.join_us

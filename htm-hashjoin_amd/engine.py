@@ -113,6 +113,11 @@ class HashJoinContext:
         self._check(lib.hj_prj_join_dev(self._h, C.c_void_p(dR_ptr), rSize,
                                         C.c_void_p(dS_ptr) if dS_ptr else None, sSize))
 
+    def join(self, dR_ptr, rSize, dS_ptr, sSize):
+        """Build + probe by the reserved algo; "auto" samples R for locality and picks atomic or prj."""
+        self._check(lib.hj_join_dev(self._h, C.c_void_p(dR_ptr), rSize,
+                                    C.c_void_p(dS_ptr) if dS_ptr else None, sSize))
+
     def checksums(self):
         self._check(lib.hj_checksums_dev(self._h))
 

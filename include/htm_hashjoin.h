@@ -51,7 +51,12 @@ typedef enum {
     HJ_ALGO_NOCC   = 0,  /* NoCCHashBuild   (NoCCHashBuild.hpp:13-151)   */
     HJ_ALGO_ATOMIC = 1,  /* AtomicHashBuild (AtomicHashBuild.hpp:14-157) */
     HJ_ALGO_HTM    = 2,  /* HTMHashBuild    (HTMHashBuild.hpp:54-464)    */
-    HJ_ALGO_PRJ    = 3   /* mc PRO          (mc/src/parallel_radix_join.c:1305) */
+    HJ_ALGO_PRJ    = 3,  /* mc PRO          (mc/src/parallel_radix_join.c:1305) */
+    HJ_ALGO_AUTO   = 4   /* the reference's adaptive idea (README.md:6, the sampling pre-round of
+                            HTMHashBuild.hpp:98-154 and its 0.4 % / 2 % thresholds :209-210): sample R for
+                            locality; with locality run the no-partition path (HJ_ALGO_ATOMIC, LDS-window
+                            build), otherwise the radix join (HJ_ALGO_PRJ). hj_result.algoUsed says which;
+                            totalMatches agrees between the two whenever R has unique keys */
 } hj_algo;
 
 /* Mirrors the trailing arguments of the reference signatures
@@ -100,7 +105,10 @@ typedef struct {
     double   buildPhaseA_us;  /* buildVariant 2: device time of k_build_own alone
                                  (build_us also covers k_clear_unowned and
                                  k_build_deferred)                                   */
-    uint64_t reserved[2];
+    uint32_t algoUsed;        /* hj_algo that produced this result (differs from
+                                 hj_params.algo only for HJ_ALGO_AUTO)               */
+    uint32_t reserved0;
+    uint64_t reserved[1];
 } hj_result;
 
 typedef struct hj_ctx hj_ctx;
@@ -147,6 +155,11 @@ int hj_probe_dev(hj_ctx *ctx, const uint64_t *dS, uint64_t sSize);
  * R-side only, checksum only). */
 int hj_prj_join_dev(hj_ctx *ctx, const uint64_t *dR, uint64_t rSize,
                     const uint64_t *dS, uint64_t sSize);
+/* Build + probe of dR x dS by whatever hj_reserve was given: HJ_ALGO_NOCC/ATOMIC/HTM = hj_build_dev(idxBase 0) then
+ * hj_probe_dev; HJ_ALGO_PRJ = hj_prj_join_dev; HJ_ALGO_AUTO = one locality pre-round over dR (k_sample_locality, one
+ * small device->host read-back) and then one of the two. Asynchronous apart from that read-back. */
+int hj_join_dev(hj_ctx *ctx, const uint64_t *dR, uint64_t rSize,
+                const uint64_t *dS, uint64_t sSize);
 /* The untimed reductions of NoCCHashBuild.hpp:85-113 (table sums). Async. */
 int hj_checksums_dev(hj_ctx *ctx);
 /* Waits for the stream and returns counters + timings of the calls above. */

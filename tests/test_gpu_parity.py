@@ -86,6 +86,36 @@ def test_auto_variant_follows_locality(ctx):
         check_oa(got, oracle.build_probe_seq(R, Sx, 4))
 
 
+def test_algo_auto_switches_between_table_and_radix_join(ctx):
+    """HJ_ALGO_AUTO (the reference's adaptive idea, HTMHashBuild.hpp:98-154): inputs with locality take the
+    no-partition path and give the open-addressing result bit for bit, inputs without it take the radix join and give
+    PRJ's; on unique keys both agree with each other (totalMatches = |R|)."""
+    n = 1 << 20
+    for dist, window, expect in (("uniform", 16, "atomic"), ("local_shuffle", 1024, "atomic"), ("sorted", 16, "atomic"),
+                                 ("shuffle", 16, "prj"), ("local_shuffle", 1 << 19, "prj")):
+        R = oracle.generate_data(dist, n, n, window)
+        S = oracle.relS_for(dist, R)
+        got = ctx.run("auto", R, S)
+        assert got["algoUsed"] == expect, (dist, window, got["algoUsed"])
+        if expect == "atomic":
+            assert got["buildVariant"] == 2
+            check_oa(got, oracle.build_probe_seq(R, S, 4))
+        else:
+            want = oracle.prj_join(R, S, got["radixBits"])
+            assert (got["totalMatches"], got["prjChecksum"]) == (want["matches"], want["checksum"])
+            assert got["totalMatches"] == n
+    # split API: hj_reserve("auto") + hj_join_dev on device pointers, R only
+    R = oracle.generate_data("shuffle", n)
+    with hj.HashJoinContext(0) as c2:
+        dR = c2.dev_alloc(n * 8)
+        c2.copy_h2d(dR, R)
+        c2.reserve("auto", n, 0)
+        c2.join(dR, n, 0, 0)
+        got = c2.fetch()
+        assert got["algoUsed"] == "prj" and got["totalMatches"] == 0
+        assert got["prjChecksum"] == oracle.prj_join(R, None, got["radixBits"])["checksum"]
+
+
 def test_unaligned_device_pointers(ctx):
     """R and S handed over at an odd tuple offset (8-byte, not 16-byte aligned), through the
     split device-pointer API (hj_reserve / hj_build_dev / hj_probe_dev / hj_fetch_result)."""
@@ -349,5 +379,9 @@ def test_main_cli_on_gpu():
         "htm", 16, 0, 1048576, 549756338176, 549756338176)
     j = run("--algo", "atomic", "--rSize", 65536, "--dataDistr", "sorted", "--probe", 0)                 # ENABLE_PROBE 0
     assert "totalMatches" not in j and j["conflicts"] == 0
+    j = run("--algo", "auto", "--rSize", 1048576, "--dataDistr", "local_shuffle", "--shuffleRange", 1024)
+    assert (j["algoUsed"], j["conflicts"], j["totalMatches"], j["outputSum"]) == ("atomic", 0, 1048576, 549756338176)
+    j = run("--algo", "auto", "--rSize", 1048576, "--dataDistr", "shuffle", "--radixBits", 14)
+    assert (j["algoUsed"], j["totalMatches"], j["results"]) == ("prj", 1048576, 33030144)
     j = run("--algo", "prj", "--rSize", 1048576, "--dataDistr", "shuffle", "--radixBits", 14)
     assert j["totalMatches"] == 1048576 and j["results"] == 33030144                                      # mc PRO "Results"
