@@ -78,9 +78,10 @@ def _declare(lib):
         "hj_checksums_dev": ([vp], i32),
         "hj_fetch_result": ([vp, P(hj_result)], i32),
         "hj_export_table": ([vp, vp, u64], i32),
-        "hj_shard_histogram_dev": ([vp, vp, u64, u32, u32, u64, vp], i32),
-        "hj_shard_scatter_dev": ([vp, vp, u64, u32, u32, u64, vp, u64, u32, vp], i32),
-        "hj_build_packed_dev": ([vp, vp, u64, u32, u32, u64], i32),
+        "hj_shard_histogram_dev": ([vp, vp, u64, u32, u32, vp], i32),
+        "hj_shard_scatter_dev": ([vp, vp, u64, u32, u32, vp, vp], i32),
+        "hj_build_keys_dev": ([vp, vp, u64, u32, u64], i32),
+        "hj_probe_keys_dev": ([vp, vp, u64], i32),
         "hj_dev_alloc": ([vp, u64, P(vp)], i32),
         "hj_dev_free": ([vp, vp], i32),
         "hj_copy_h2d": ([vp, vp, vp, u64], i32),

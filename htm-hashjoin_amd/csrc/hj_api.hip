@@ -27,7 +27,7 @@ struct hj_ctx {
     uint64_t* table = nullptr;
     uint64_t tableCapSlots = 0;   // allocated slots incl. slack
     uint64_t tableSize = 0;       // live table (2*rSize) of the last build
-    uint32_t strip = 0, shardId = 0; // slot format of the current table (hj_device.h); 0,0 unless radix-sharded
+    uint32_t hshift = 0;             // home-slot shift of the current table (hj_device.h); 0 unless it is a radix shard
     uint64_t rSize = 0, sSize = 0;
     bool built = false;
     // ownership build (variant 2)
@@ -247,7 +247,7 @@ int hj_reserve(hj_ctx* c, const hj_params* params, uint64_t rSize, uint64_t sSiz
     if (rc) return rc;
     if (params->buildVariant > 2) return fail(c, HJ_ERR_INVALID, "hj_reserve: buildVariant must be 0, 1 or 2");
     if (params->buildVariant != 1 && own_supported(2 * rSize)) {
-        // 1/8 headroom: a radix shard may receive slightly more than its nominal share (hj_build_packed_dev)
+        // 1/8 headroom: a radix shard may receive slightly more than its nominal share (hj_build_keys_dev)
         const size_t ob = own_owner_bytes(2 * rSize), qb = own_queue_bytes(rSize + rSize / 8);
         if (ob > c->capOwner) {
             if (c->ownerBuf) { HJ_HIP(c, hipFree(c->ownerBuf)); c->ownerBuf = nullptr; c->capOwner = 0; }
@@ -264,22 +264,22 @@ int hj_reserve(hj_ctx* c, const hj_params* params, uint64_t rSize, uint64_t sSiz
 // Locality pre-round: 256 sample tiles; the LDS-window kernel is worth taking if it would have to defer at
 // most 1/12 of the tuples (measured at 2^27, local_shuffle: W=2^11 defers 3.8 % and runs 2.1 ms against
 // 5.7 ms for the global-atomic kernel; W=2^12 defers 36 % and runs 12.9 ms against 5.8).
-static int sample_is_local(hj_ctx* c, const uint64_t* d, uint64_t n, uint64_t tableSize, uint32_t strip, bool* local)
+static int sample_is_local(hj_ctx* c, const void* d, bool key32, uint64_t n, uint64_t tableSize, uint32_t hshift, bool* local)
 {
     const uint32_t nSample = 256;
-    launch_sample_locality(d, n, tableSize, strip, nSample, c->fitCount, c->stream);
+    launch_sample_locality(d, key32, n, tableSize, hshift, nSample, c->fitCount, c->stream);
     HJ_HIP(c, hipMemcpyAsync(c->hFit, c->fitCount, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
     HJ_HIP(c, hipStreamSynchronize(c->stream));
     *local = (uint64_t)c->hFit[0] * 12 <= (uint64_t)c->hFit[1];
     return HJ_OK;
 }
 
-// Shared by hj_build_dev (DataGen tuples) and hj_build_packed_dev (index-packed tuples).
-static int build_common(hj_ctx* c, const uint64_t* d, uint64_t n, bool packed, uint32_t strip, uint32_t shard,
+// Shared by hj_build_dev (DataGen tuples) and hj_build_keys_dev (bare keys of a radix shard).
+static int build_common(hj_ctx* c, const void* d, bool key32, uint64_t n, uint32_t hshift,
                         uint64_t tableSize, uint64_t idxBase)
 {
     HJ_HIP(c, hipSetDevice(c->device));
-    c->rSize = n; c->sSize = 0; c->tableSize = tableSize; c->strip = strip; c->shardId = shard;
+    c->rSize = n; c->sSize = 0; c->tableSize = tableSize; c->hshift = hshift;
     for (bool& b : c->evSet) b = false;
     c->prjRan = false;
     HJ_HIP(c, hipMemsetAsync(c->dCtr, 0, sizeof(Counters), c->stream));
@@ -294,7 +294,7 @@ static int build_common(hj_ctx* c, const uint64_t* d, uint64_t n, bool packed, u
         variant = 1;
         if (canOwn && n) {
             bool local = false;
-            if ((rc = sample_is_local(c, d, n, tableSize, strip, &local))) return rc;
+            if ((rc = sample_is_local(c, d, key32, n, tableSize, hshift, &local))) return rc;
             if (local) variant = 2;
         }
     }
@@ -302,15 +302,14 @@ static int build_common(hj_ctx* c, const uint64_t* d, uint64_t n, bool packed, u
     c->algoUsed = c->params.algo == HJ_ALGO_AUTO ? (uint32_t)HJ_ALGO_ATOMIC : c->params.algo;
     if (variant == 2) {
         if ((rc = record(c, EV_BUILD0))) return rc;
-        launch_build_own(d, n, packed, strip, shard, c->table, tableSize, probe_len(c->params), idxBase, c->ownerBuf,
+        launch_build_own(d, key32, n, hshift, c->table, tableSize, probe_len(c->params), idxBase, c->ownerBuf,
                          c->queueBuf, c->queueCount, c->dCtr, c->ev[EV_BUILD_A], c->stream);
         c->evSet[EV_BUILD_A] = true;
     } else {
         launch_fill_empty(c->table, tableSize + kTableSlack, c->stream);
         launch_set_full_range(tableSize, c->dCtr, c->stream);
         if ((rc = record(c, EV_BUILD0))) return rc;
-        if (packed) { if (n) launch_build_packed(d, n, c->table, tableSize, strip, shard, probe_len(c->params), c->dCtr, c->stream); }
-        else launch_build_atomic_min(d, n, c->table, tableSize, probe_len(c->params), idxBase, c->dCtr, c->stream);
+        if (n) launch_build_atomic_min(d, key32, n, c->table, tableSize, hshift, probe_len(c->params), idxBase, c->dCtr, c->stream);
     }
     if ((rc = record(c, EV_BUILD1))) return rc;
     HJ_HIP(c, hipGetLastError());
@@ -325,19 +324,18 @@ int hj_build_dev(hj_ctx* c, const uint64_t* dR, uint64_t rSize, uint64_t idxBase
     if (!is_pow2(rSize) || 2 * rSize + kTableSlack > c->tableCapSlots)
         return fail(c, HJ_ERR_STATE, "hj_build_dev: hj_reserve() not called for this rSize");
     if (idxBase + rSize > (1ull << 32)) return fail(c, HJ_ERR_INVALID, "hj_build_dev: index range exceeds 32 bits");
-    return build_common(c, dR, rSize, false, 0, 0, 2 * rSize, idxBase);
+    return build_common(c, dR, false, rSize, 0, 2 * rSize, idxBase);
 }
 
-int hj_build_packed_dev(hj_ctx* c, const uint64_t* dPacked, uint64_t n, uint32_t stripBits, uint32_t shardId,
-                        uint64_t tableSize)
+int hj_build_keys_dev(hj_ctx* c, const uint32_t* dKeys, uint64_t n, uint32_t homeShift, uint64_t tableSize)
 {
-    if (!c || (!dPacked && n)) return HJ_ERR_INVALID;
-    if (c->params.algo == HJ_ALGO_PRJ) return fail(c, HJ_ERR_STATE, "hj_build_packed_dev: context is reserved for PRJ");
-    if (stripBits > 6 || shardId >= (1u << stripBits))
-        return fail(c, HJ_ERR_INVALID, "hj_build_packed_dev: stripBits must be in [0,6] and shardId < 2^stripBits");
+    if (!c || (!dKeys && n)) return HJ_ERR_INVALID;
+    if (c->params.algo == HJ_ALGO_PRJ) return fail(c, HJ_ERR_STATE, "hj_build_keys_dev: context is reserved for PRJ");
+    if (homeShift > 6) return fail(c, HJ_ERR_INVALID, "hj_build_keys_dev: homeShift must be in [0,6]");
     if (!is_pow2(tableSize) || tableSize + kTableSlack > c->tableCapSlots)
-        return fail(c, HJ_ERR_STATE, "hj_build_packed_dev: hj_reserve() not called for this table size");
-    return build_common(c, dPacked, n, true, stripBits, shardId, tableSize, 0);
+        return fail(c, HJ_ERR_STATE, "hj_build_keys_dev: hj_reserve() not called for this table size");
+    if (n > (1ull << 32)) return fail(c, HJ_ERR_INVALID, "hj_build_keys_dev: index range exceeds 32 bits");
+    return build_common(c, dKeys, true, n, homeShift, tableSize, 0);
 }
 
 int hj_probe_dev(hj_ctx* c, const uint64_t* dS, uint64_t sSize)
@@ -347,10 +345,24 @@ int hj_probe_dev(hj_ctx* c, const uint64_t* dS, uint64_t sSize)
     HJ_HIP(c, hipSetDevice(c->device));
     int rc;
     if ((rc = record(c, EV_PROBE0))) return rc;
-    if (sSize) launch_probe(dS, sSize, c->table, c->tableSize, c->strip, probe_len(c->params), c->dCtr, c->stream);
+    if (sSize) launch_probe(dS, false, sSize, c->table, c->tableSize, c->hshift, probe_len(c->params), c->dCtr, c->stream);
     if ((rc = record(c, EV_PROBE1))) return rc;
     HJ_HIP(c, hipGetLastError());
     c->sSize += sSize;
+    return HJ_OK;
+}
+
+int hj_probe_keys_dev(hj_ctx* c, const uint32_t* dKeys, uint64_t n)
+{
+    if (!c || (!dKeys && n)) return HJ_ERR_INVALID;
+    if (!c->built) return fail(c, HJ_ERR_STATE, "hj_probe_keys_dev: no table (build first)");
+    HJ_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = record(c, EV_PROBE0))) return rc;
+    if (n) launch_probe(dKeys, true, n, c->table, c->tableSize, c->hshift, probe_len(c->params), c->dCtr, c->stream);
+    if ((rc = record(c, EV_PROBE1))) return rc;
+    HJ_HIP(c, hipGetLastError());
+    c->sSize += n;
     return HJ_OK;
 }
 
@@ -399,7 +411,7 @@ int hj_join_dev(hj_ctx* c, const uint64_t* dR, uint64_t rSize, const uint64_t* d
         bool local = false;
         const bool canOwn = own_supported(2 * rSize) && c->capOwner >= own_owner_bytes(2 * rSize) &&
                             c->capQueue >= own_queue_bytes(rSize);
-        if (canOwn && c->params.buildVariant != 1 && (rc = sample_is_local(c, dR, rSize, 2 * rSize, 0, &local))) return rc;
+        if (canOwn && c->params.buildVariant != 1 && (rc = sample_is_local(c, dR, false, rSize, 2 * rSize, 0, &local))) return rc;
         prj = !local;
         force = 2;
     }
@@ -418,7 +430,7 @@ int hj_checksums_dev(hj_ctx* c)
     HJ_HIP(c, hipSetDevice(c->device));
     // zero the two sums so the call is idempotent
     HJ_HIP(c, hipMemsetAsync(&c->dCtr->tableSumHalf, 0, 2 * sizeof(unsigned long long), c->stream));
-    launch_table_sums(c->table, c->tableSize, c->tableSize / 2, c->strip, c->shardId, c->dCtr, c->stream);
+    launch_table_sums(c->table, c->tableSize, c->tableSize / 2, c->dCtr, c->stream);
     HJ_HIP(c, hipGetLastError());
     return HJ_OK;
 }
@@ -477,7 +489,7 @@ int hj_export_table(hj_ctx* c, uint64_t* host_table, uint64_t tableSize)
     HJ_HIP(c, hipMemcpy(&k, c->dCtr, sizeof(k), hipMemcpyDeviceToHost));
     const uint64_t lo = k.validLo, hi = k.validHiEx + 512 < tableSize ? k.validHiEx + 512 : tableSize;
     for (uint64_t i = 0; i < tableSize; ++i)
-        host_table[i] = (i < lo || i >= hi || host_table[i] == kEmpty) ? 0 : full_key(slot_key(host_table[i], c->strip), c->strip, c->shardId);
+        host_table[i] = (i < lo || i >= hi || host_table[i] == kEmpty) ? 0 : (uint32_t)host_table[i];
     return HJ_OK;
 }
 
@@ -510,7 +522,7 @@ static int shard_check(hj_ctx* c, const char* who, uint64_t n, uint32_t nShards,
 }
 
 int hj_shard_histogram_dev(hj_ctx* c, const uint64_t* dIn, uint64_t n, uint32_t nShards, uint32_t mode,
-                           uint64_t /*tableSize*/, uint64_t* dCounts)
+                           uint64_t* dCounts)
 {
     if (!c || (!dIn && n) || !dCounts) return HJ_ERR_INVALID;
     int rc = shard_check(c, "hj_shard_histogram_dev: nShards must be a power of two <= 64", n, nShards, mode);
@@ -533,20 +545,16 @@ int hj_shard_histogram_dev(hj_ctx* c, const uint64_t* dIn, uint64_t n, uint32_t 
 }
 
 int hj_shard_scatter_dev(hj_ctx* c, const uint64_t* dIn, uint64_t n, uint32_t nShards, uint32_t mode,
-                         uint64_t /*tableSize*/, const uint64_t* dCounts, uint64_t packIdxBase, uint32_t stripBits,
-                         uint64_t* dOut)
+                         const uint64_t* dCounts, uint32_t* dOutKeys)
 {
-    if (!c || (!dIn && n) || !dCounts || (!dOut && n)) return HJ_ERR_INVALID;
+    if (!c || (!dIn && n) || !dCounts || (!dOutKeys && n)) return HJ_ERR_INVALID;
     int rc = shard_check(c, "hj_shard_scatter_dev: nShards must be a power of two <= 64", n, nShards, mode);
     if (rc) return rc;
-    if (stripBits > 6) return fail(c, HJ_ERR_INVALID, "hj_shard_scatter_dev: stripBits must be in [0,6]");
-    if (packIdxBase != ~0ull && packIdxBase + n > (1ull << (32 + stripBits)))
-        return fail(c, HJ_ERR_INVALID, "hj_shard_scatter_dev: index range exceeds 32 + stripBits bits");
     hj_ctx::ShardPlan* slot = nullptr;
     for (auto& sp : c->shard) if (sp.in == dIn && sp.n == n && sp.nShards == nShards && sp.work) slot = &sp;
     if (!slot) return fail(c, HJ_ERR_STATE, "hj_shard_scatter_dev: call hj_shard_histogram_dev on this input first");
     HJ_HIP(c, hipSetDevice(c->device));
-    launch_shard_scatter_ordered(dIn, n, nShards, slot->work, packIdxBase, stripBits, dOut, c->stream);
+    launch_shard_scatter_ordered(dIn, n, nShards, slot->work, dOutKeys, c->stream);
     HJ_HIP(c, hipGetLastError());
     slot->in = nullptr;   // consumed
     return HJ_OK;

@@ -41,6 +41,7 @@
 #include "hj_device.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace hj {
 
@@ -78,8 +79,8 @@ constexpr uint32_t kDrainAt = HJ_DRAIN_AT;            // run retry rounds once t
 constexpr int kQCap = 128;                        // per-wavefront retry queue entries (LDS)
 
 // owner[blk]: 0 = free, otherwise (workgroup id + 1).
-// PACKED = false: R holds DataGen tuples (value = key), index = idxBase + position.
-// PACKED = true : R holds (globalIdx << (32 - strip) | key') from hj_shard_scatter_dev (slot format: hj_device.h).
+// KEY32 = false: R holds DataGen tuples (value = key); KEY32 = true: bare 32-bit keys (what the multi-GPU exchange
+// delivers). Either way index = idxBase + position and home slot = (key >> hshift) & mask (hj_device.h).
 //
 // rocprof showed the first versions VALU-issue bound (120 VALU + 90 SALU instructions per 64
 // tuples on unique keys, 5x that on duplicate-heavy `uniform`, LDS <10 % busy), so the insert is
@@ -92,10 +93,10 @@ constexpr int kQCap = 128;                        // per-wavefront retry queue e
 //               atomicMin) run on 64 queue entries at a time, so every round is dense regardless of
 //               how long individual probe/displacement chains get.
 // All per-tuple arithmetic is 32-bit: key = low word, slot numbers < 2^32, value = {key, index}.
-template <bool PACKED, int ABL = 0>
+template <bool KEY32, int ABL = 0>
 __global__ void __launch_bounds__(kOwnThreads, 4)
-k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
-            uint64_t* __restrict__ table, uint64_t mask, uint32_t strip, uint32_t shard, uint32_t probeLen, uint64_t idxBase,
+k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
+            uint64_t* __restrict__ table, uint64_t mask, uint32_t hshift, uint32_t probeLen, uint64_t idxBase,
             unsigned int* __restrict__ owner, DeferredEntry* __restrict__ queue,
             unsigned long long* __restrict__ queueCount, Counters* __restrict__ ctr)
 {
@@ -110,11 +111,11 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
     const uint64_t ce = (cb + chunkLen < n) ? cb + chunkLen : n;
     const uint32_t clen = (uint32_t)(ce - cb);                        // chunk length (< 2^32)
     const uint32_t mask32 = (uint32_t)mask;                           // tableSize <= 2^32 slots
-    const uint32_t kmask = key_mask(strip);                           // key' bits of a slot's low word (all ones unless sharded)
     const uint32_t numBlocks = (uint32_t)((mask + 1) >> kBlkShift);   // tableSize >= kWinSlots, host-checked
     const uint32_t me = blockIdx.x + 1;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t* __restrict__ Rc = R + cb;                          // this chunk
+    using Elem = typename std::conditional<KEY32, uint32_t, uint64_t>::type;
+    const Elem* __restrict__ Rc = static_cast<const Elem*>(Rv) + cb;   // this chunk
     const uint32_t idx0 = (uint32_t)(idxBase + cb);                    // index of the chunk's first tuple (fits 32 bits, host-checked)
     uint32_t* const myQPos = qPos[wave]; uint32_t* const myQLo = qLo[wave]; uint32_t* const myQHi = qHi[wave];
 
@@ -141,8 +142,8 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
         const bool has = lane < take;
         // lanes >= take read stale-but-in-bounds queue entries (qCount + lane < kQCap) and ignore them
         uint32_t pos = myQPos[qCount + lane], mlo = myQLo[qCount + lane], mhi = myQHi[qCount + lane];
-        const uint32_t key = mlo & kmask;                                  // key'
-        uint32_t budget = probeLen - ((pos - (key & mask32)) & mask32);
+        const uint32_t key = mlo;
+        uint32_t budget = probeLen - ((pos - ((key >> hshift) & mask32)) & mask32);
         const uint32_t blk = pos >> kBlkShift;
         const bool ownOk = (blk - wb < kWinBlocks) & (((ownedMask >> (blk & (kWinBlocks - 1))) & 1u) != 0);
         const bool drop0 = has & (budget == 0);                           // NoCCHashBuild.hpp:57-58
@@ -172,7 +173,7 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
         pos = fail ? ((pos + 1) & mask32) : pos;
         const bool again = recheck | fail;
         const bool dropped = drop0 | drop1;
-        drops += dropped ? 1u : 0u; dropSum += dropped ? full_key(key, strip, shard) : 0ull;
+        drops += dropped ? 1u : 0u; dropSum += dropped ? (unsigned long long)key : 0ull;
         // deferred tuples leave for the global queue (one returning atomic per round that has any)
         const unsigned long long dm = __ballot(toDefer);
         if (dm) {
@@ -224,12 +225,12 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
 #pragma unroll
         for (int j = 0; j < kPerThread; ++j) {
             const bool in = full | (tb + tOff + 64 * j < clen);
-            const bool okKey = PACKED ? (full_key(klo[j] & kmask, strip, shard) != 0) : ((khi[j] == 0) & (klo[j] != 0));
+            const bool okKey = (khi[j] == 0) & (klo[j] != 0);
             const bool ok = in & okKey;
-            inSum += in ? (PACKED ? (unsigned long long)full_key(klo[j] & kmask, strip, shard) : (unsigned long long)pack64(khi[j], klo[j])) : 0ull;
+            inSum += in ? (unsigned long long)pack64(khi[j], klo[j]) : 0ull;
             bad += (in & !okKey) ? 1u : 0u;
             liveMask |= ok ? (1u << j) : 0u;
-            const uint32_t hb = ((klo[j] & kmask) & mask32) >> kBlkShift;
+            const uint32_t hb = ((klo[j] >> hshift) & mask32) >> kBlkShift;
             myMin = (ok & (hb < myMin)) ? hb : myMin;
         }
         myMin = wave_min_u32(myMin);
@@ -284,7 +285,7 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
         if (haveWin && !(ABL & 8)) {
 #pragma unroll
             for (int j = 0; j < kPerThread; ++j) {
-                const uint32_t home = (klo[j] & kmask) & mask32;
+                const uint32_t home = (klo[j] >> hshift) & mask32;
                 const uint32_t hb = home >> kBlkShift;
                 const bool lv = (liveMask >> j) & 1u;
                 uint32_t r0 = (lv & (hb - wb < kWinBlocks)) ? (hb & (kWinBlocks - 1)) : 0xFFu;
@@ -334,8 +335,8 @@ k_build_own(const uint64_t* __restrict__ R, uint64_t n, uint64_t chunkLen,
             while (qCount >= kDrainAt) retry_round();                   // keep room for one full step
             const bool lv = (liveMask >> j) & 1u;
             uint32_t mlo = klo[j];
-            uint32_t mhi = PACKED ? khi[j] : (idx0 + tb + tOff + 64 * j);
-            uint32_t pos = (klo[j] & kmask) & mask32;
+            uint32_t mhi = idx0 + tb + tOff + 64 * j;
+            uint32_t pos = (klo[j] >> hshift) & mask32;
             const uint32_t blk = pos >> kBlkShift;
             const bool own = lv & (blk - wb < kWinBlocks) & (((ownedMask >> (blk & (kWinBlocks - 1))) & 1u) != 0);
             const uint64_t mine = pack64(mhi, mlo);
@@ -423,15 +424,22 @@ k_clear_unowned(uint64_t* __restrict__ table, const unsigned int* __restrict__ o
     const uint32_t b0 = (uint32_t)(ctr->validLo >> kBlkShift);
     uint32_t b1 = (uint32_t)(ctr->validHiEx >> kBlkShift) + 1;     // exclusive; one block past the probed range
     if (b1 > numBlocks) b1 = numBlocks;
-    // one wavefront per block: 64 lanes x 16 B x 4 = 4 KiB
+    // a wavefront looks at 64 owner words at a time (one per lane) and then fills the unclaimed blocks among
+    // them, each as 64 lanes x 16 B x 4 = 4 KiB (one dependent owner load per block made this kernel
+    // latency bound: 100 us at 2^30 for 8 MB of owner words)
     const uint32_t wavesPerGrid = gridDim.x * (kBlock / 64);
     const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
-    for (uint32_t blk = b0 + wave; blk < b1; blk += wavesPerGrid) {
-        if (owner[blk] != 0) continue;
-        ulonglong2* dst = reinterpret_cast<ulonglong2*>(table + ((uint64_t)blk << kBlkShift));
+    for (uint64_t base = (uint64_t)b0 + (uint64_t)wave * 64; base < b1; base += (uint64_t)wavesPerGrid * 64) {
+        const uint64_t mine = base + lane;
+        unsigned long long m = __ballot(mine < b1 && owner[mine] == 0);
+        while (m) {
+            const uint32_t j = (uint32_t)__ffsll((long long)m) - 1;
+            m &= m - 1;
+            ulonglong2* dst = reinterpret_cast<ulonglong2*>(table + ((base + j) << kBlkShift));
 #pragma unroll
-        for (uint32_t v = 0; v < kBlkSlots / 2 / 64; ++v) dst[v * 64 + lane] = e;
+            for (uint32_t v = 0; v < kBlkSlots / 2 / 64; ++v) dst[v * 64 + lane] = e;
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x < kTableSlack) table[tableSize + threadIdx.x] = kEmpty;
 }
@@ -439,7 +447,7 @@ k_clear_unowned(uint64_t* __restrict__ table, const unsigned int* __restrict__ o
 // Phase B: finish the probe walk of every deferred tuple with global atomics.
 __global__ void __launch_bounds__(kBlock)
 k_build_deferred(const DeferredEntry* __restrict__ queue, const unsigned long long* __restrict__ queueCount,
-                 uint64_t* __restrict__ table, uint64_t mask, uint32_t strip, uint32_t shard, uint32_t probeLen,
+                 uint64_t* __restrict__ table, uint64_t mask, uint32_t hshift, uint32_t probeLen,
                  Counters* __restrict__ ctr)
 {
     const unsigned long long nq = *queueCount;
@@ -448,16 +456,16 @@ k_build_deferred(const DeferredEntry* __restrict__ queue, const unsigned long lo
          i += (unsigned long long)gridDim.x * kBlock) {
         uint64_t mine = queue[i].packed;
         uint64_t pos = queue[i].pos;
-        const uint64_t home0 = slot_key(mine, strip) & mask;
+        const uint64_t home0 = home_slot((uint32_t)mine, hshift, mask);
         uint32_t budget = probeLen - (uint32_t)((pos - home0) & mask);
         for (;;) {
-            if (budget == 0) { drops += 1; dropSum += full_key(slot_key(mine, strip), strip, shard); break; }
+            if (budget == 0) { drops += 1; dropSum += (uint32_t)mine; break; }
             const unsigned long long old =
                 atomicMin(reinterpret_cast<unsigned long long*>(table + pos), (unsigned long long)mine);
             if (old == kEmpty || old == mine) break;
             if (old > mine) {
                 mine = old;
-                const uint64_t home = slot_key(old, strip) & mask;
+                const uint64_t home = home_slot((uint32_t)old, hshift, mask);
                 budget = probeLen - ((uint32_t)((pos - home) & mask) + 1);
             } else {
                 budget -= 1;
@@ -481,10 +489,13 @@ k_build_deferred(const DeferredEntry* __restrict__ queue, const unsigned long lo
 // tuples that would fall outside the LDS window k_build_own would place for their tile
 // (window base = the tile's lowest home block - kBackBlocks) and therefore be deferred.
 // out[0] = tuples outside, out[1] = tuples looked at.
+template <bool KEY32>
 __global__ void __launch_bounds__(kBlock)
-k_sample_locality(const uint64_t* __restrict__ R, uint64_t n, uint64_t mask, uint32_t strip, uint32_t nSample,
+k_sample_locality(const void* __restrict__ Rv, uint64_t n, uint64_t mask, uint32_t hshift, uint32_t nSample,
                   unsigned int* __restrict__ out)
 {
+    using Elem = typename std::conditional<KEY32, uint32_t, uint64_t>::type;
+    const Elem* __restrict__ R = static_cast<const Elem*>(Rv);
     __shared__ unsigned int sMinBlk, sOutside;
     const uint64_t tiles = (n + kOwnTile - 1) / kOwnTile;
     for (uint32_t s = blockIdx.x; s < nSample; s += gridDim.x) {
@@ -494,7 +505,7 @@ k_sample_locality(const uint64_t* __restrict__ R, uint64_t n, uint64_t mask, uin
         __syncthreads();
         uint32_t lo = 0xFFFFFFFFu;
         for (uint64_t i = b + threadIdx.x; i < e; i += kBlock) {
-            const uint32_t hb = (uint32_t)(((uint64_t)slot_key(R[i], strip) & mask) >> kBlkShift);
+            const uint32_t hb = (uint32_t)(home_slot((uint32_t)R[i], hshift, mask) >> kBlkShift);
             lo = hb < lo ? hb : lo;
         }
         lo = wave_min_u32(lo);
@@ -503,7 +514,7 @@ k_sample_locality(const uint64_t* __restrict__ R, uint64_t n, uint64_t mask, uin
         const uint32_t wbase = sMinBlk > kBackBlocks ? sMinBlk - kBackBlocks : 0;
         uint32_t outside = 0;
         for (uint64_t i = b + threadIdx.x; i < e; i += kBlock) {      // second sweep hits L2
-            const uint32_t hb = (uint32_t)(((uint64_t)slot_key(R[i], strip) & mask) >> kBlkShift);
+            const uint32_t hb = (uint32_t)(home_slot((uint32_t)R[i], hshift, mask) >> kBlkShift);
             outside += (hb - wbase >= kWinBlocks) ? 1u : 0u;
         }
 #pragma unroll
@@ -520,15 +531,19 @@ size_t own_queue_bytes(uint64_t rSize) { return (rSize + 64) * sizeof(DeferredEn
 size_t own_owner_bytes(uint64_t tableSize) { return ((tableSize >> kBlkShift) + 1) * sizeof(unsigned int); }
 bool own_supported(uint64_t tableSize) { return tableSize >= (uint64_t)kWinSlots; }
 
-void launch_sample_locality(const uint64_t* R, uint64_t n, uint64_t tableSize, uint32_t strip, uint32_t nSample,
+void launch_sample_locality(const void* R, bool key32, uint64_t n, uint64_t tableSize, uint32_t hshift, uint32_t nSample,
                             unsigned int* fitCount, hipStream_t s)
 {
     (void)hipMemsetAsync(fitCount, 0, 2 * sizeof(unsigned int), s);
-    hipLaunchKernelGGL(k_sample_locality, dim3(nSample < 256 ? nSample : 256), dim3(kBlock), 0, s,
-                       R, n, tableSize - 1, strip, nSample, fitCount);
+    if (key32)
+        hipLaunchKernelGGL(k_sample_locality<true>, dim3(nSample < 256 ? nSample : 256), dim3(kBlock), 0, s,
+                           R, n, tableSize - 1, hshift, nSample, fitCount);
+    else
+        hipLaunchKernelGGL(k_sample_locality<false>, dim3(nSample < 256 ? nSample : 256), dim3(kBlock), 0, s,
+                           R, n, tableSize - 1, hshift, nSample, fitCount);
 }
 
-void launch_build_own(const uint64_t* R, uint64_t n, bool packed, uint32_t strip, uint32_t shard, uint64_t* table,
+void launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshift, uint64_t* table,
                       uint64_t tableSize, uint32_t probeLen, uint64_t idxBase, void* ownerBuf, void* queueBuf,
                       unsigned long long* queueCount, Counters* ctr, hipEvent_t evPhaseA, hipStream_t s)
 {
@@ -557,9 +572,9 @@ void launch_build_own(const uint64_t* R, uint64_t n, bool packed, uint32_t strip
     chunkLen = (chunkLen + kOwnTile - 1) / kOwnTile * kOwnTile;
     if (chunkLen < (uint64_t)kOwnTile * 4) chunkLen = (uint64_t)kOwnTile * 4;
     const unsigned grid = (unsigned)((n + chunkLen - 1) / chunkLen);
-    if (packed)
+    if (key32)
         hipLaunchKernelGGL(k_build_own<true>, dim3(grid), dim3(kOwnThreads), kWinSlots * sizeof(uint64_t), s,
-                           R, n, chunkLen, table, tableSize - 1, strip, shard, probeLen, idxBase,
+                           R, n, chunkLen, table, tableSize - 1, hshift, probeLen, idxBase,
                            static_cast<unsigned int*>(ownerBuf), static_cast<DeferredEntry*>(queueBuf), queueCount, ctr);
     else {
         // timing-only ablations (results wrong by construction), selected by HJ_OWN_ABLATE
@@ -567,7 +582,7 @@ void launch_build_own(const uint64_t* R, uint64_t n, bool packed, uint32_t strip
         if (abl < 0) { const char* e = getenv("HJ_OWN_ABLATE"); abl = e ? atoi(e) : 0; }
 #define HJ_OWN_LAUNCH(A)                                                                                          \
         hipLaunchKernelGGL((k_build_own<false, A>), dim3(grid), dim3(kOwnThreads), kWinSlots * sizeof(uint64_t), s, \
-                           R, n, chunkLen, table, tableSize - 1, strip, shard, probeLen, idxBase,                         \
+                           R, n, chunkLen, table, tableSize - 1, hshift, probeLen, idxBase,                                \
                            static_cast<unsigned int*>(ownerBuf), static_cast<DeferredEntry*>(queueBuf), queueCount, ctr)
         switch (abl) {
             case 1: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(1); break;
@@ -587,7 +602,7 @@ void launch_build_own(const uint64_t* R, uint64_t n, bool packed, uint32_t strip
     hipLaunchKernelGGL(k_clear_unowned, dim3(2048), dim3(kBlock), 0, s, table,
                        static_cast<const unsigned int*>(ownerBuf), ctr, numBlocks, tableSize);
     hipLaunchKernelGGL(k_build_deferred, dim3(1024), dim3(kBlock), 0, s,
-                       static_cast<const DeferredEntry*>(queueBuf), queueCount, table, tableSize - 1, strip, shard, probeLen, ctr);
+                       static_cast<const DeferredEntry*>(queueBuf), queueCount, table, tableSize - 1, hshift, probeLen, ctr);
 }
 
 }  // namespace hj

@@ -14,12 +14,11 @@ constexpr uint64_t kEmpty = ~0ull;
 // (NoCCHashBuild.hpp:74-75 does curSlot++ without & tableMask).
 constexpr uint32_t kTableSlack = 16;
 
-// Radix-sharded input (multi-GPU): all keys of a shard share their low `strip` bits (= the shard number),
-// so a slot stores key' = key >> strip in its low (32 - strip) bits and gives the freed bits to the
-// index: slot = (globalIndex << (32 - strip)) | key'. strip = 0 is the single-GPU format (idx << 32 | key).
-__host__ __device__ inline uint32_t key_mask(uint32_t strip) { return 0xFFFFFFFFu >> strip; }
-__host__ __device__ inline uint32_t slot_key(uint64_t slot, uint32_t strip) { return (uint32_t)slot & key_mask(strip); }
-__host__ __device__ inline uint64_t full_key(uint32_t keyPrime, uint32_t strip, uint32_t shard) { return ((uint64_t)keyPrime << strip) | shard; }
+// Home slot of a key: (key >> hshift) & (tableSize - 1). hshift = 0 is the reference's hash (NoCCHashBuild.hpp:41);
+// a radix shard of a multi-GPU join holds only keys with the same low log2(shards) bits, which therefore carry no
+// information inside the shard and are shifted out of the slot number (hshift = log2(shards)). The slot still stores
+// the whole key.
+__host__ __device__ inline uint64_t home_slot(uint32_t key, uint32_t hshift, uint64_t mask) { return (uint64_t)(key >> hshift) & mask; }
 
 constexpr int kBlock = 256;          // 4 wavefronts of 64
 constexpr int kWave = 64;
@@ -49,34 +48,32 @@ struct Counters {
 };
 
 // ---- launch wrappers (defined in hj_kernels.hip) ---------------------------
+// Inputs come in two element formats: 8-byte DataGen tuples (key32 = false; value = key, payload bits must be 0)
+// or bare 32-bit keys (key32 = true; what the multi-GPU exchange delivers). Index of element i = idxBase + i.
 void launch_fill_empty(uint64_t* table, uint64_t nSlots, hipStream_t s);
-void launch_build_atomic_min(const uint64_t* R, uint64_t n, uint64_t* table,
-                             uint64_t tableSize, uint32_t probeLen, uint64_t idxBase,
-                             Counters* ctr, hipStream_t s);
-void launch_build_packed(const uint64_t* packed, uint64_t n, uint64_t* table, uint64_t tableSize,
-                         uint32_t strip, uint32_t shard, uint32_t probeLen, Counters* ctr, hipStream_t s);
-void launch_probe(const uint64_t* S, uint64_t n, const uint64_t* table, uint64_t tableSize,
-                  uint32_t strip, uint32_t probeLen, Counters* ctr, hipStream_t s);
-void launch_table_sums(const uint64_t* table, uint64_t tableSize, uint64_t halfSlots, uint32_t strip, uint32_t shard,
-                       Counters* ctr, hipStream_t s);
+void launch_build_atomic_min(const void* R, bool key32, uint64_t n, uint64_t* table, uint64_t tableSize, uint32_t hshift,
+                             uint32_t probeLen, uint64_t idxBase, Counters* ctr, hipStream_t s);
+void launch_probe(const void* S, bool key32, uint64_t n, const uint64_t* table, uint64_t tableSize, uint32_t hshift,
+                  uint32_t probeLen, Counters* ctr, hipStream_t s);
+void launch_table_sums(const uint64_t* table, uint64_t tableSize, uint64_t halfSlots, Counters* ctr, hipStream_t s);
 // Marks the whole table valid (variant 1 clears and may touch all of it).
 void launch_set_full_range(uint64_t tableSize, Counters* ctr, hipStream_t s);
-// multi-GPU destination split (defined in hj_prj.hip: one order-preserving radix pass)
+// multi-GPU destination split (defined in hj_prj.hip: one order-preserving radix pass, tuples in, keys out)
 size_t shard_work_bytes(uint64_t n, uint32_t nShards);
 void launch_shard_hist(const uint64_t* in, uint64_t n, uint32_t nShards, void* work, unsigned long long* counts,
                        hipStream_t s);
-void launch_shard_scatter_ordered(const uint64_t* in, uint64_t n, uint32_t nShards, void* work, uint64_t packIdxBase,
-                                  uint32_t strip, uint64_t* out, hipStream_t s);
+void launch_shard_scatter_ordered(const uint64_t* in, uint64_t n, uint32_t nShards, void* work, uint32_t* outKeys,
+                                  hipStream_t s);
 
 // ---- ownership build (defined in hj_build_own.hip) ---------------------------
 size_t own_queue_bytes(uint64_t rSize);
 size_t own_owner_bytes(uint64_t tableSize);
 bool   own_supported(uint64_t tableSize);
-void launch_sample_locality(const uint64_t* R, uint64_t n, uint64_t tableSize, uint32_t strip, uint32_t nSample,
+void launch_sample_locality(const void* R, bool key32, uint64_t n, uint64_t tableSize, uint32_t hshift, uint32_t nSample,
                             unsigned int* fitCount, hipStream_t s);
 // phase A (LDS window) -> clear of unowned blocks -> phase B (deferred tuples).
 // Writes every table slot exactly once: no separate launch_fill_empty needed.
-void launch_build_own(const uint64_t* R, uint64_t n, bool packed, uint32_t strip, uint32_t shard, uint64_t* table,
+void launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshift, uint64_t* table,
                       uint64_t tableSize, uint32_t probeLen, uint64_t idxBase, void* ownerBuf, void* queueBuf,
                       unsigned long long* queueCount, Counters* ctr, hipEvent_t evPhaseA, hipStream_t s);
 

@@ -24,6 +24,8 @@
 
 #include "hj_device.h"
 
+#include <type_traits>
+
 namespace hj {
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
@@ -71,18 +73,17 @@ void launch_fill_empty(uint64_t* table, uint64_t nSlots, hipStream_t s)
 // ---------------------------------------------------------------------------
 // build
 // ---------------------------------------------------------------------------
-// Inserts `mine` = (index << (32 - strip) | key') starting at slot `pos` with `budget`
-// probes left (slot format: hj_device.h). The home slot of a tuple is key' & homeMask,
-// homeMask = tableSize - 1; `shard` only serves to report dropped keys in full.
+// Inserts `mine` = (index << 32 | key) starting at slot `pos` with `budget` probes left. The home slot
+// of a key is (key >> hshift) & homeMask, homeMask = tableSize - 1 (hj_device.h).
 __device__ __forceinline__ void insert_priority(uint64_t* __restrict__ table, uint64_t homeMask,
-                                                uint32_t strip, uint32_t shard, uint32_t probeLen,
+                                                uint32_t hshift, uint32_t probeLen,
                                                 uint64_t mine, uint64_t pos, uint32_t budget,
                                                 unsigned long long& drops, unsigned long long& dropSum)
 {
     for (;;) {
         if (budget == 0) {  // NoCCHashBuild.hpp:57-58
             drops += 1;
-            dropSum += full_key(slot_key(mine, strip), strip, shard);
+            dropSum += (uint32_t)mine;
             return;
         }
         const unsigned long long old =
@@ -92,7 +93,7 @@ __device__ __forceinline__ void insert_priority(uint64_t* __restrict__ table, ui
             // displaced a later tuple: carry it on from the next slot with the
             // budget it has left there
             mine = old;
-            const uint64_t home = slot_key(old, strip) & homeMask;
+            const uint64_t home = home_slot((uint32_t)old, hshift, homeMask);
             const uint32_t disp = (uint32_t)((pos - home) & homeMask);
             budget = probeLen - (disp + 1);
         } else {
@@ -102,36 +103,46 @@ __device__ __forceinline__ void insert_priority(uint64_t* __restrict__ table, ui
     }
 }
 
+// t = the element zero-extended to 64 bits (a tuple as it is, or a bare key)
 __device__ __forceinline__ void build_one(uint64_t t, uint64_t idx, uint64_t* __restrict__ table,
-                                          uint64_t mask, uint32_t probeLen,
+                                          uint64_t mask, uint32_t hshift, uint32_t probeLen,
                                           unsigned long long& drops, unsigned long long& dropSum,
                                           unsigned long long& inSum, unsigned long long& bad)
 {
     inSum += t;
     if ((t >> 32) != 0 || t == 0) { bad += 1; return; }
     const uint64_t mine = (idx << 32) | t;
-    insert_priority(table, mask, 0, 0, probeLen, mine, t & mask, probeLen, drops, dropSum);
+    insert_priority(table, mask, hshift, probeLen, mine, home_slot((uint32_t)t, hshift, mask), probeLen, drops, dropSum);
 }
 
+// KEY32 = false: R holds 8-byte tuples (16-byte loads over the aligned body, head/tail element by one
+// thread); KEY32 = true: bare keys, one 4-byte load per lane (this kernel is bound by its atomics).
+template <bool KEY32>
 __global__ void __launch_bounds__(kBlock)
-k_build_atomic_min(const uint64_t* __restrict__ R, uint64_t n, uint64_t* __restrict__ table,
-                   uint64_t mask, uint32_t probeLen, uint64_t idxBase, Counters* __restrict__ ctr)
+k_build_atomic_min(const void* __restrict__ Rv, uint64_t n, uint64_t* __restrict__ table,
+                   uint64_t mask, uint32_t hshift, uint32_t probeLen, uint64_t idxBase, Counters* __restrict__ ctr)
 {
     unsigned long long drops = 0, dropSum = 0, inSum = 0, bad = 0;
-    // 16-byte loads over the aligned body; head/tail element by one thread
-    const uint64_t head = (n > 0 && (reinterpret_cast<uintptr_t>(R) & 8)) ? 1 : 0;
-    const ulonglong2* R2 = reinterpret_cast<const ulonglong2*>(R + head);
-    const uint64_t nv = (n - head) >> 1;
-    for (uint64_t v = (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (uint64_t)gridDim.x * kBlock) {
-        const ulonglong2 t = R2[v];
-        const uint64_t i = head + 2 * v;
-        build_one(t.x, idxBase + i, table, mask, probeLen, drops, dropSum, inSum, bad);
-        build_one(t.y, idxBase + i + 1, table, mask, probeLen, drops, dropSum, inSum, bad);
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (head) build_one(R[0], idxBase, table, mask, probeLen, drops, dropSum, inSum, bad);
-        const uint64_t tail = head + 2 * nv;
-        if (tail < n) build_one(R[tail], idxBase + tail, table, mask, probeLen, drops, dropSum, inSum, bad);
+    if constexpr (KEY32) {
+        const uint32_t* K = static_cast<const uint32_t*>(Rv);
+        for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock)
+            build_one(K[i], idxBase + i, table, mask, hshift, probeLen, drops, dropSum, inSum, bad);
+    } else {
+        const uint64_t* R = static_cast<const uint64_t*>(Rv);
+        const uint64_t head = (n > 0 && (reinterpret_cast<uintptr_t>(R) & 8)) ? 1 : 0;
+        const ulonglong2* R2 = reinterpret_cast<const ulonglong2*>(R + head);
+        const uint64_t nv = (n - head) >> 1;
+        for (uint64_t v = (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (uint64_t)gridDim.x * kBlock) {
+            const ulonglong2 t = R2[v];
+            const uint64_t i = head + 2 * v;
+            build_one(t.x, idxBase + i, table, mask, hshift, probeLen, drops, dropSum, inSum, bad);
+            build_one(t.y, idxBase + i + 1, table, mask, hshift, probeLen, drops, dropSum, inSum, bad);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (head) build_one(R[0], idxBase, table, mask, hshift, probeLen, drops, dropSum, inSum, bad);
+            const uint64_t tail = head + 2 * nv;
+            if (tail < n) build_one(R[tail], idxBase + tail, table, mask, hshift, probeLen, drops, dropSum, inSum, bad);
+        }
     }
     flush_counter(&ctr->conflicts, drops);
     flush_counter(&ctr->conflictSum, dropSum);
@@ -139,54 +150,30 @@ k_build_atomic_min(const uint64_t* __restrict__ R, uint64_t n, uint64_t* __restr
     flush_counter(&ctr->badKeys, bad);
 }
 
-void launch_build_atomic_min(const uint64_t* R, uint64_t n, uint64_t* table, uint64_t tableSize,
+void launch_build_atomic_min(const void* R, bool key32, uint64_t n, uint64_t* table, uint64_t tableSize, uint32_t hshift,
                              uint32_t probeLen, uint64_t idxBase, Counters* ctr, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_build_atomic_min, dim3(grid_for(n / 2 + 1, kBlock)), dim3(kBlock), 0, s,
-                       R, n, table, tableSize - 1, probeLen, idxBase, ctr);
-}
-
-// Build from pre-packed (globalIdx << (32 - strip) | key') tuples (radix-sharded input after the
-// exchange, hj_shard_scatter_dev). Same protocol, priority = global index.
-__global__ void __launch_bounds__(kBlock)
-k_build_packed(const uint64_t* __restrict__ P, uint64_t n, uint64_t* __restrict__ table,
-               uint64_t homeMask, uint32_t strip, uint32_t shard, uint32_t probeLen, Counters* __restrict__ ctr)
-{
-    unsigned long long drops = 0, dropSum = 0, inSum = 0, bad = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
-        const uint64_t p = P[i];
-        const uint32_t kp = slot_key(p, strip);
-        const uint64_t key = full_key(kp, strip, shard);
-        inSum += key;
-        if (key == 0) { bad += 1; continue; }
-        insert_priority(table, homeMask, strip, shard, probeLen, p, kp & homeMask, probeLen, drops, dropSum);
-    }
-    flush_counter(&ctr->conflicts, drops);
-    flush_counter(&ctr->conflictSum, dropSum);
-    flush_counter(&ctr->inputSum, inSum);
-    flush_counter(&ctr->badKeys, bad);
-}
-
-void launch_build_packed(const uint64_t* packed, uint64_t n, uint64_t* table, uint64_t tableSize,
-                         uint32_t strip, uint32_t shard, uint32_t probeLen, Counters* ctr, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_build_packed, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s,
-                       packed, n, table, tableSize - 1, strip, shard, probeLen, ctr);
+    if (key32)
+        hipLaunchKernelGGL(k_build_atomic_min<true>, dim3(grid_for(n + 1, kBlock)), dim3(kBlock), 0, s,
+                           R, n, table, tableSize - 1, hshift, probeLen, idxBase, ctr);
+    else
+        hipLaunchKernelGGL(k_build_atomic_min<false>, dim3(grid_for(n / 2 + 1, kBlock)), dim3(kBlock), 0, s,
+                           R, n, table, tableSize - 1, hshift, probeLen, idxBase, ctr);
 }
 
 // ---------------------------------------------------------------------------
 // probe
 // ---------------------------------------------------------------------------
+// sk = the S element zero-extended to 64 bits
 __device__ __forceinline__ uint32_t probe_one(uint64_t sk, const uint64_t* __restrict__ table,
-                                              uint64_t mask, uint32_t strip, uint32_t probeLen,
+                                              uint64_t mask, uint32_t hshift, uint32_t probeLen,
                                               uint64_t validLo, uint64_t validHiEx)
 {
-    // outside the valid range no stored tuple can have this home slot (hj_device.h, Counters)
-    // a tuple with payload bits set can match nothing; S tuples of a shard carry that shard's low key bits
-    const uint32_t kp = (uint32_t)sk >> strip;
-    const uint64_t home = kp & mask;
+    // a tuple with payload bits set can match nothing; outside the valid range no stored tuple can
+    // have this home slot (hj_device.h, Counters)
+    const uint32_t key = (uint32_t)sk;
+    const uint64_t home = home_slot(key, hshift, mask);
     if ((sk >> 32) != 0 || home < validLo || home >= validHiEx) return 0;
-    const uint32_t km = key_mask(strip);
     // NoCCHashBuild.hpp:70-79: walk at most probeLen consecutive slots from the
     // home slot, stop at the first empty one, count slots equal to the tuple.
     const uint64_t* p = table + home;
@@ -194,55 +181,71 @@ __device__ __forceinline__ uint32_t probe_one(uint64_t sk, const uint64_t* __res
     if (probeLen == 4) {
         const uint64_t a = p[0], b = p[1], c = p[2], d = p[3];  // slack slots make this safe
         const bool ea = a != kEmpty, eb = ea && b != kEmpty, ec = eb && c != kEmpty, ed = ec && d != kEmpty;
-        m += (ea && ((uint32_t)a & km) == kp);
-        m += (eb && ((uint32_t)b & km) == kp);
-        m += (ec && ((uint32_t)c & km) == kp);
-        m += (ed && ((uint32_t)d & km) == kp);
+        m += (ea && (uint32_t)a == key);
+        m += (eb && (uint32_t)b == key);
+        m += (ec && (uint32_t)c == key);
+        m += (ed && (uint32_t)d == key);
     } else {
         for (uint32_t j = 0; j < probeLen; ++j) {
             const uint64_t v = p[j];
             if (v == kEmpty) break;
-            m += (((uint32_t)v & km) == kp);
+            m += ((uint32_t)v == key);
         }
     }
     return m;
 }
 
+// 16-byte loads over the aligned body (2 tuples or 4 keys per lane), the few elements before and after
+// it by one thread.
+template <bool KEY32>
 __global__ void __launch_bounds__(kBlock)
-k_probe(const uint64_t* __restrict__ S, uint64_t n, const uint64_t* __restrict__ table, uint64_t mask,
-        uint32_t strip, uint32_t probeLen, Counters* __restrict__ ctr)
+k_probe(const void* __restrict__ Sv, uint64_t n, const uint64_t* __restrict__ table, uint64_t mask,
+        uint32_t hshift, uint32_t probeLen, Counters* __restrict__ ctr)
 {
+    using Elem = typename std::conditional<KEY32, uint32_t, uint64_t>::type;
+    constexpr uint64_t EPV = 16 / sizeof(Elem);
     unsigned long long matches = 0;
     const uint64_t validLo = ctr->validLo, validHiEx = ctr->validHiEx;
-    const uint64_t head = (n > 0 && (reinterpret_cast<uintptr_t>(S) & 8)) ? 1 : 0;
-    const ulonglong2* S2 = reinterpret_cast<const ulonglong2*>(S + head);
-    const uint64_t nv = (n - head) >> 1;
+    const Elem* S = static_cast<const Elem*>(Sv);
+    uint64_t head = ((16 - (reinterpret_cast<uintptr_t>(S) & 15)) & 15) / sizeof(Elem);
+    if (head > n) head = n;
+    const uint4* S4 = reinterpret_cast<const uint4*>(S + head);
+    const uint64_t nv = (n - head) / EPV;
     for (uint64_t v = (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (uint64_t)gridDim.x * kBlock) {
-        const ulonglong2 t = S2[v];
-        matches += probe_one(t.x, table, mask, strip, probeLen, validLo, validHiEx);
-        matches += probe_one(t.y, table, mask, strip, probeLen, validLo, validHiEx);
+        const uint4 t = S4[v];
+        if constexpr (KEY32) {
+            matches += probe_one(t.x, table, mask, hshift, probeLen, validLo, validHiEx);
+            matches += probe_one(t.y, table, mask, hshift, probeLen, validLo, validHiEx);
+            matches += probe_one(t.z, table, mask, hshift, probeLen, validLo, validHiEx);
+            matches += probe_one(t.w, table, mask, hshift, probeLen, validLo, validHiEx);
+        } else {
+            matches += probe_one(((uint64_t)t.y << 32) | t.x, table, mask, hshift, probeLen, validLo, validHiEx);
+            matches += probe_one(((uint64_t)t.w << 32) | t.z, table, mask, hshift, probeLen, validLo, validHiEx);
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (head) matches += probe_one(S[0], table, mask, strip, probeLen, validLo, validHiEx);
-        const uint64_t tail = head + 2 * nv;
-        if (tail < n) matches += probe_one(S[tail], table, mask, strip, probeLen, validLo, validHiEx);
+        for (uint64_t i = 0; i < head; ++i) matches += probe_one(S[i], table, mask, hshift, probeLen, validLo, validHiEx);
+        for (uint64_t i = head + nv * EPV; i < n; ++i) matches += probe_one(S[i], table, mask, hshift, probeLen, validLo, validHiEx);
     }
     flush_counter(&ctr->matches, matches);
 }
 
-void launch_probe(const uint64_t* S, uint64_t n, const uint64_t* table, uint64_t tableSize,
-                  uint32_t strip, uint32_t probeLen, Counters* ctr, hipStream_t s)
+void launch_probe(const void* S, bool key32, uint64_t n, const uint64_t* table, uint64_t tableSize, uint32_t hshift,
+                  uint32_t probeLen, Counters* ctr, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_probe, dim3(grid_for(n / 2 + 1, kBlock)), dim3(kBlock), 0, s,
-                       S, n, table, tableSize - 1, strip, probeLen, ctr);
+    if (key32)
+        hipLaunchKernelGGL(k_probe<true>, dim3(grid_for(n / 4 + 1, kBlock)), dim3(kBlock), 0, s,
+                           S, n, table, tableSize - 1, hshift, probeLen, ctr);
+    else
+        hipLaunchKernelGGL(k_probe<false>, dim3(grid_for(n / 2 + 1, kBlock)), dim3(kBlock), 0, s,
+                           S, n, table, tableSize - 1, hshift, probeLen, ctr);
 }
 
 // ---------------------------------------------------------------------------
 // table checksums
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
-k_table_sums(const uint64_t* __restrict__ table, uint64_t tableSize, uint64_t halfSlots, uint32_t strip, uint32_t shard,
-             Counters* __restrict__ ctr)
+k_table_sums(const uint64_t* __restrict__ table, uint64_t tableSize, uint64_t halfSlots, Counters* __restrict__ ctr)
 {
     unsigned long long half = 0, full = 0;
     const ulonglong2* t2 = reinterpret_cast<const ulonglong2*>(table);
@@ -253,8 +256,8 @@ k_table_sums(const uint64_t* __restrict__ table, uint64_t tableSize, uint64_t ha
     const uint64_t nv = hi >> 1;
     for (uint64_t v = (lo >> 1) + (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (uint64_t)gridDim.x * kBlock) {
         const ulonglong2 t = t2[v];
-        const uint64_t a = (t.x == kEmpty) ? 0 : full_key(slot_key(t.x, strip), strip, shard);
-        const uint64_t b = (t.y == kEmpty) ? 0 : full_key(slot_key(t.y, strip), strip, shard);
+        const uint64_t a = (t.x == kEmpty) ? 0 : (uint32_t)t.x;
+        const uint64_t b = (t.y == kEmpty) ? 0 : (uint32_t)t.y;
         full += a + b;
         if (2 * v < halfSlots) half += a;
         if (2 * v + 1 < halfSlots) half += b;
@@ -263,11 +266,10 @@ k_table_sums(const uint64_t* __restrict__ table, uint64_t tableSize, uint64_t ha
     flush_counter(&ctr->tableSumFull, full);
 }
 
-void launch_table_sums(const uint64_t* table, uint64_t tableSize, uint64_t halfSlots, uint32_t strip, uint32_t shard,
-                       Counters* ctr, hipStream_t s)
+void launch_table_sums(const uint64_t* table, uint64_t tableSize, uint64_t halfSlots, Counters* ctr, hipStream_t s)
 {
     hipLaunchKernelGGL(k_table_sums, dim3(grid_for(tableSize / 2, kBlock * 4)), dim3(kBlock), 0, s,
-                       table, tableSize, halfSlots, strip, shard, ctr);
+                       table, tableSize, halfSlots, ctr);
 }
 
 __global__ void k_set_full_range(uint64_t tableSize, Counters* __restrict__ ctr)

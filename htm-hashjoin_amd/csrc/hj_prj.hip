@@ -42,8 +42,8 @@ struct PassParams {
     uint32_t chunkLen;          // multiple of kTile
     const uint32_t* chunkBase;  // [nSeg + 1] exclusive prefix of chunks per segment
     uint32_t shift, fan;        // bin = (key >> shift) & (fan - 1)
-    uint64_t packIdxBase;       // ~0: tuples move unchanged; else output = (packIdxBase + i) << (32 - strip) | key >> strip
-    uint32_t strip;             // (slot format of hj_device.h)
+    uint32_t zeroBad;           // shard split only: a tuple with payload bits set counts and travels as key 0, which the
+                                // receiving build reports (HJ_ERR_KEY_RANGE); PRJ reads the key word alone, as mc does
 };
 
 // chunkBase[s] = sum_{t<s} ceil(len_t / chunkLen). nSeg <= 256: one thread.
@@ -137,15 +137,56 @@ k_radix_hist(const void* __restrict__ in, PassParams p, uint32_t* __restrict__ h
     const uint32_t fmask = p.fan - 1;
     // 16-byte aligned sweep: start at the vector that holds element `begin`
     const uint4* in4 = reinterpret_cast<const uint4*>(in);
+    if (p.fan <= 16) {
+        // few bins (the multi-GPU split: fan = number of shards): 64 lanes adding to a handful of LDS words
+        // serialise on the address (measured: 2.4 TB/s at fan 1 against 5.8 TB/s at fan 256), so count with
+        // ballots into wave-uniform registers instead and add once per wavefront at the end
+        uint32_t wc[16];
+#pragma unroll
+        for (int b = 0; b < 16; ++b) wc[b] = 0;
+        bool live = false;
+        auto tally = [&](uint32_t key, uint32_t at) {
+            const bool ok = live && at >= r.begin && at < r.end;
+            const uint32_t bin = (key >> p.shift) & fmask;
+#pragma unroll
+            for (int b = 0; b < 16; ++b)
+                if (b < (int)p.fan) wc[b] += (uint32_t)__popcll(__ballot(ok && bin == (uint32_t)b));
+        };
+        const uint32_t vEnd = (uint32_t)(((uint64_t)r.end + EPV - 1) / EPV);
+        // whole wavefronts iterate together (ballots need every lane): round the trip count up
+        for (uint32_t v0 = r.begin / EPV; v0 < vEnd; v0 += kBlock) {
+            const uint32_t v = v0 + threadIdx.x;
+            live = v < vEnd;
+            const uint4 t = in4[live ? v : vEnd - 1];
+            const uint32_t i = v * EPV;
+            if constexpr (IN32) {
+                tally(t.x, i); tally(t.y, i + 1); tally(t.z, i + 2); tally(t.w, i + 3);
+            } else {
+                tally((p.zeroBad && t.y) ? 0u : t.x, i);
+                tally((p.zeroBad && t.w) ? 0u : t.z, i + 1);
+            }
+        }
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int b = 0; b < 16; ++b)
+                if (b < (int)p.fan && wc[b]) atomicAdd(&h[b], wc[b]);
+        }
+        __syncthreads();
+        if (threadIdx.x < p.fan) hist[hist_index(p, r, threadIdx.x)] = h[threadIdx.x];
+        return;
+    }
     for (uint32_t v = r.begin / EPV + threadIdx.x; (uint64_t)v * EPV < r.end; v += kBlock) {
         const uint4 t = in4[v];
         const uint32_t i = v * EPV;
         auto one = [&](uint32_t key, uint32_t at) {
             if (at >= r.begin && at < r.end) atomicAdd(&h[(key >> p.shift) & fmask], 1u);
         };
-        one(vec_key<IN32, 0>(t), i);
-        one(vec_key<IN32, 1>(t), i + 1);
-        if constexpr (IN32) { one(vec_key<IN32, 2>(t), i + 2); one(vec_key<IN32, 3>(t), i + 3); }
+        if constexpr (IN32) {
+            one(t.x, i); one(t.y, i + 1); one(t.z, i + 2); one(t.w, i + 3);
+        } else {
+            one((p.zeroBad && t.y) ? 0u : t.x, i);
+            one((p.zeroBad && t.w) ? 0u : t.z, i + 1);
+        }
     }
     __syncthreads();
     if (threadIdx.x < p.fan) hist[hist_index(p, r, threadIdx.x)] = h[threadIdx.x];
@@ -247,7 +288,7 @@ k_seg_offsets(PassParams p, const uint32_t* __restrict__ scanned, uint32_t nTota
 //   NT threads, TV 16-byte loads per thread and tile -> tile = NT * TV * EPV elements.
 //   Instances: pass 1 of PRJ   tuples -> keys, 512 x 8 x 2 = 8192 per tile (128-byte runs at fan 256)
 //              pass 2 of PRJ   keys -> keys,   512 x 4 x 4 = 8192 per tile
-//              shard scatter   tuples -> (packed) tuples, 256 x 8 x 2 = 4096 per tile
+//              shard scatter   the pass-1 instance with fan-out = number of shards
 // ---------------------------------------------------------------------------
 template <bool IN32, bool OUT32, int NT, int TV, bool PF = true, int WPE = 1>
 __global__ void __launch_bounds__(NT, WPE)
@@ -280,7 +321,6 @@ k_radix_scatter(const void* __restrict__ in, void* __restrict__ outv, PassParams
     const ChunkRange r = chunk_range(p, c);
     const uint32_t fmask = p.fan - 1;
     const uint32_t len = r.end - r.begin;
-    const bool packed = !OUT32 && p.packIdxBase != ~0ull;
     if (threadIdx.x < kMaxFan) {
         tileCnt[threadIdx.x] = 0;
         cursor[threadIdx.x] = threadIdx.x < p.fan ? scanned[hist_index(p, r, threadIdx.x)] : 0;
@@ -333,8 +373,7 @@ k_radix_scatter(const void* __restrict__ in, void* __restrict__ outv, PassParams
             const uint32_t bin = (key >> p.shift) & fmask;
             const bool ok = rel < len;
             if constexpr (OUT32) tv[slot] = key;
-            else tv[slot] = packed           // shard scatter: the input index travels above the (stripped) key
-                                ? (((p.packIdxBase + r.begin + rel) << (32 - p.strip)) | (key >> p.strip)) : tuple;
+            else tv[slot] = tuple;
             okMask |= ok ? (1u << slot) : 0u;
             br[slot] = (bin << 16) | atomicAdd(&tileCnt[bin], ok ? 1u : 0u);
         };
@@ -384,16 +423,7 @@ k_radix_scatter(const void* __restrict__ in, void* __restrict__ outv, PassParams
         const uint32_t valid = sValid;
         auto emit = [&](uint32_t q) {
             const OutT t = stage[q + (q >> kPadShift)];
-            // bin of staged position q: packed tuples no longer carry their bin bits, so look it up
-            // (largest bin with tileOff[bin] <= q; fan <= 256 -> 8 steps of binary search in LDS)
-            uint32_t bin;
-            if (!packed) {
-                bin = ((uint32_t)t >> p.shift) & fmask;
-            } else {
-                uint32_t lo = 0, hi = p.fan;
-                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tileOff[mid] <= q) lo = mid; else hi = mid; }
-                bin = lo;
-            }
+            const uint32_t bin = ((uint32_t)t >> p.shift) & fmask;
             out[delta[bin] + q] = t;
         };
         if (valid == TILE) {
@@ -664,7 +694,7 @@ void run_pass(const void* in, bool in32, uint32_t* out, uint64_t n, const uint32
     const uint32_t fan = 1u << bits;
     const PassLayout l = pass_layout(n, nSeg, fan);
     hipLaunchKernelGGL(k_chunk_base, dim3(1), dim3(64), 0, s, segIn, nSeg, l.chunkLen, w.chunkBase);
-    PassParams p{segIn, nSeg, l.chunkLen, w.chunkBase, shift, fan, ~0ull, 0u};
+    PassParams p{segIn, nSeg, l.chunkLen, w.chunkBase, shift, fan, 0u};
     // entries past the live chunks must be zero for the scan to be a prefix of live data only
     hipMemsetAsync(w.hist, 0, sizeof(uint32_t) * l.histEntries, s);
     if (in32) hipLaunchKernelGGL(k_radix_hist<true>, dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s, in, p, w.hist);
@@ -728,10 +758,120 @@ void launch_prj(const PrjPlan& pl, const PrjBuffers& buf, const uint64_t* R, uin
 
 // ---------------------------------------------------------------------------
 // multi-GPU destination split (hj_shard_histogram_dev / hj_shard_scatter_dev): one radix pass on
-// the low log2(nShards) key bits. Chunk order is preserved (scan-based cursors, no atomics across
-// workgroups), so a near-sorted input stays near-sorted inside every destination and the receiving
-// rank's locality pre-round still picks the LDS-window build.
+// the low log2(nShards) key bits, tuples in, bare keys out, and STABLE: inside a destination the keys
+// keep their input order exactly. The join's semantics are "insert in input order"; the receiving rank
+// takes a key's position in its receive buffer as that order, so the scatter may not permute anything
+// (the PRJ scatter above ranks with LDS atomics and is only stable tile by tile -- the radix join does
+// not care). It also keeps a near-sorted input near-sorted, so the receiver's locality pre-round still
+// picks the LDS-window build.
+//
+// Ranking without atomics: lane l of wavefront w holds, for k = 0..15, the tile's element k*512 + 64 w + l,
+// so (k, w, l) is input order. For one k a wavefront finds, per lane, the lanes with the same
+// destination (log2(fan) ballots) -- its rank among them is a popcount of the lower lanes, their
+// number goes to cnt[bin][k][w]. An exclusive scan of cnt in exactly that order gives every
+// (bin, k, w) group its place in the tile's staged order.
 // ---------------------------------------------------------------------------
+constexpr int kStabThreads = 512;
+constexpr int kStabPer = 16;                                   // tuples per thread per tile
+constexpr int kStabTile = kStabThreads * kStabPer;             // 8192
+constexpr int kStabGroups = kStabPer * (kStabThreads / 64);    // (k, wavefront) groups per tile = 128
+constexpr int kStabMaxFan = 64;
+
+__global__ void __launch_bounds__(kStabThreads, 4)
+k_shard_scatter_stable(const uint64_t* __restrict__ in, uint32_t* __restrict__ out, PassParams p,
+                       const uint32_t* __restrict__ scanned)
+{
+    extern __shared__ uint32_t stab[];              // cnt[fan][kStabGroups], then stage[kStabTile + kStabTile/32 + 1]
+    uint32_t* const cnt = stab;
+    const uint32_t nCnt = p.fan * kStabGroups;
+    uint32_t* const stage = stab + nCnt;
+    __shared__ unsigned int delta[kStabMaxFan];     // write cursor of the bin - its offset in the staged tile
+    __shared__ unsigned int cursor[kStabMaxFan];
+    __shared__ uint32_t wsum[kStabThreads / 64];
+    constexpr uint32_t kDump = kStabTile + (kStabTile >> 5);
+
+    const uint32_t c = blockIdx.x;
+    if (c >= p.chunkBase[p.nSeg]) return;
+    const ChunkRange r = chunk_range(p, c);
+    const uint32_t fmask = p.fan - 1;
+    const uint32_t len = r.end - r.begin;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int bits = 0;
+    while ((1u << bits) < p.fan) ++bits;
+    if (threadIdx.x < p.fan) cursor[threadIdx.x] = scanned[hist_index(p, r, threadIdx.x)];
+    const uint32_t perThread = nCnt / kStabThreads;               // fan * 128 / 512 = fan / 4 (fan >= 4) ...
+    const uint32_t items = perThread ? perThread : 1;             // ... or 1 with some threads idle (fan < 4)
+    __syncthreads();
+
+    for (uint32_t tb = 0; tb < len; tb += kStabTile) {
+        for (uint32_t i = threadIdx.x; i < nCnt; i += kStabThreads) cnt[i] = 0;
+        uint32_t key[kStabPer], rk4[kStabPer / 4];    // ranks are < 64: four to a register
+        uint32_t okMask = 0;
+#pragma unroll
+        for (int k = 0; k < kStabPer / 4; ++k) rk4[k] = 0;
+#pragma unroll
+        for (int k = 0; k < kStabPer; ++k) {
+            const uint32_t rel = tb + (uint32_t)k * kStabThreads + threadIdx.x;
+            const bool ok = rel < len;
+            const uint64_t t = ok ? in[(uint64_t)r.begin + rel] : 0ull;
+            key[k] = (t >> 32) ? 0u : (uint32_t)t;                 // payload bits set: see PassParams::zeroBad
+            okMask |= ok ? (1u << k) : 0u;
+        }
+        __syncthreads();                                          // cnt is zero
+#pragma unroll
+        for (int k = 0; k < kStabPer; ++k) {
+            const bool ok = (okMask >> k) & 1u;
+            const uint32_t bin = key[k] & fmask;
+            unsigned long long peers = __ballot(ok);
+            for (int b = 0; b < bits; ++b) {
+                const bool bit = (bin >> b) & 1u;
+                const unsigned long long m = __ballot(bit);
+                peers &= bit ? m : ~m;
+            }
+            const uint32_t rk = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+            rk4[k / 4] |= rk << (8 * (k % 4));
+            if (ok && rk == 0) cnt[(bin * kStabPer + k) * (kStabThreads / 64) + wave] = (uint32_t)__popcll(peers);
+        }
+        __syncthreads();
+        {   // exclusive scan of cnt[0..nCnt) in place, `items` consecutive entries per thread
+            const uint32_t base = threadIdx.x * items;
+            uint32_t local = 0;
+            for (uint32_t i = 0; i < items; ++i) local += (base + i < nCnt) ? cnt[base + i] : 0u;
+            uint32_t total;
+            uint32_t ex = block_exclusive_scan<kStabThreads>(local, wsum, total);
+            for (uint32_t i = 0; i < items; ++i) {
+                if (base + i < nCnt) { const uint32_t v = cnt[base + i]; cnt[base + i] = ex; ex += v; }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < p.fan) {
+            const uint32_t off = cnt[threadIdx.x * kStabGroups];                      // first group of the bin
+            const uint32_t end = threadIdx.x + 1 < p.fan ? cnt[(threadIdx.x + 1) * kStabGroups]
+                                                         : (len - tb < (uint32_t)kStabTile ? len - tb : (uint32_t)kStabTile);
+            const uint32_t cu = cursor[threadIdx.x];
+            delta[threadIdx.x] = cu - off;
+            cursor[threadIdx.x] = cu + (end - off);
+        }
+#pragma unroll
+        for (int k = 0; k < kStabPer; ++k) {
+            const uint32_t bin = key[k] & fmask;
+            const uint32_t at = cnt[(bin * kStabPer + k) * (kStabThreads / 64) + wave] + ((rk4[k / 4] >> (8 * (k % 4))) & 0xFFu);
+            stage[((okMask >> k) & 1u) ? at + (at >> 5) : kDump] = key[k];
+        }
+        __syncthreads();
+        const uint32_t valid = len - tb < (uint32_t)kStabTile ? len - tb : (uint32_t)kStabTile;
+#pragma unroll 4
+        for (int k = 0; k < kStabPer; ++k) {
+            const uint32_t q = (uint32_t)k * kStabThreads + threadIdx.x;
+            if (q < valid) {
+                const uint32_t t = stage[q + (q >> 5)];
+                out[delta[t & fmask] + q] = t;
+            }
+        }
+        __syncthreads();                                          // stage, cnt and delta are reused by the next tile
+    }
+}
+
 namespace {
 struct ShardWork { uint32_t *seg0, *segOut, *chunkBase, *hist, *sums; };
 ShardWork shard_carve(void* base, uint64_t n, uint32_t fan)
@@ -766,7 +906,7 @@ void launch_shard_hist(const uint64_t* in, uint64_t n, uint32_t nShards, void* w
     const PassLayout l = pass_layout(n, 1, nShards);
     hipLaunchKernelGGL(k_init_seg, dim3(1), dim3(64), 0, s, w.seg0, (uint32_t)n);
     hipLaunchKernelGGL(k_chunk_base, dim3(1), dim3(64), 0, s, w.seg0, 1u, l.chunkLen, w.chunkBase);
-    PassParams p{w.seg0, 1u, l.chunkLen, w.chunkBase, 0u, nShards, ~0ull, 0u};
+    PassParams p{w.seg0, 1u, l.chunkLen, w.chunkBase, 0u, nShards, 1u};
     (void)hipMemsetAsync(w.hist, 0, sizeof(uint32_t) * l.histEntries, s);
     hipLaunchKernelGGL(k_radix_hist<false>, dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s, static_cast<const void*>(in), p, w.hist);
     hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)l.scanBlocks), dim3(kBlock), 0, s, w.hist, l.histEntries, w.sums);
@@ -776,14 +916,23 @@ void launch_shard_hist(const uint64_t* in, uint64_t n, uint32_t nShards, void* w
     hipLaunchKernelGGL(k_shard_counts, dim3(1), dim3(64), 0, s, w.segOut, nShards, counts);
 }
 
-void launch_shard_scatter_ordered(const uint64_t* in, uint64_t n, uint32_t nShards, void* work, uint64_t packIdxBase,
-                                  uint32_t strip, uint64_t* out, hipStream_t s)
+// tuples in, bare keys out, stable: the exchange moves 4 bytes per tuple and no index
+void launch_shard_scatter_ordered(const uint64_t* in, uint64_t n, uint32_t nShards, void* work, uint32_t* outKeys,
+                                  hipStream_t s)
 {
     const ShardWork w = shard_carve(work, n, nShards);
     const PassLayout l = pass_layout(n, 1, nShards);
-    PassParams p{w.seg0, 1u, l.chunkLen, w.chunkBase, 0u, nShards, packIdxBase, strip};
-    hipLaunchKernelGGL((k_radix_scatter<false, false, kBlock, 8>), dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s,
-                       static_cast<const void*>(in), static_cast<void*>(out), p, w.hist);
+    PassParams p{w.seg0, 1u, l.chunkLen, w.chunkBase, 0u, nShards, 1u};
+    const size_t lds = sizeof(uint32_t) * ((size_t)nShards * kStabGroups + kStabTile + (kStabTile >> 5) + 1);   // <= 65.1 KiB
+    static bool attrSet = false;
+    if (!attrSet) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_shard_scatter_stable),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  sizeof(uint32_t) * (kStabMaxFan * kStabGroups + kStabTile + (kStabTile >> 5) + 1));
+        attrSet = true;
+    }
+    hipLaunchKernelGGL(k_shard_scatter_stable, dim3((unsigned)l.maxChunks), dim3(kStabThreads), lds, s,
+                       in, outKeys, p, w.hist);
 }
 
 }  // namespace hj

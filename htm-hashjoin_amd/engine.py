@@ -150,17 +150,19 @@ class HashJoinContext:
     def copy_d2h(self, dst_np, src_ptr):
         self._check(lib.hj_copy_d2h(self._h, dst_np.ctypes.data, C.c_void_p(src_ptr), dst_np.nbytes))
 
-    def shard_histogram(self, d_in, n, n_shards, mode, table_size, d_counts):
-        self._check(lib.hj_shard_histogram_dev(self._h, C.c_void_p(d_in), n, n_shards, mode, table_size,
-                                               C.c_void_p(d_counts)))
+    def shard_histogram(self, d_in, n, n_shards, d_counts, mode=0):
+        self._check(lib.hj_shard_histogram_dev(self._h, C.c_void_p(d_in), n, n_shards, mode, C.c_void_p(d_counts)))
 
-    def shard_scatter(self, d_in, n, n_shards, mode, table_size, d_counts, pack_idx_base, strip_bits, d_out):
-        base = 0xFFFFFFFFFFFFFFFF if pack_idx_base is None else pack_idx_base
-        self._check(lib.hj_shard_scatter_dev(self._h, C.c_void_p(d_in), n, n_shards, mode, table_size,
-                                             C.c_void_p(d_counts), base, strip_bits, C.c_void_p(d_out)))
+    def shard_scatter(self, d_in, n, n_shards, d_counts, d_out_keys, mode=0):
+        """tuples in, bare 32-bit keys out, grouped by destination in input order"""
+        self._check(lib.hj_shard_scatter_dev(self._h, C.c_void_p(d_in), n, n_shards, mode, C.c_void_p(d_counts),
+                                             C.c_void_p(d_out_keys)))
 
-    def build_packed(self, d_packed, n, strip_bits, shard_id, table_size):
-        self._check(lib.hj_build_packed_dev(self._h, C.c_void_p(d_packed), n, strip_bits, shard_id, table_size))
+    def build_keys(self, d_keys, n, home_shift, table_size):
+        self._check(lib.hj_build_keys_dev(self._h, C.c_void_p(d_keys), n, home_shift, table_size))
+
+    def probe_keys(self, d_keys, n):
+        self._check(lib.hj_probe_keys_dev(self._h, C.c_void_p(d_keys), n))
 
 
 def _operator(algo, relR, rSize, relS, sSize, device, **kw):

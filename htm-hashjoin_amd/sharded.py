@@ -7,18 +7,19 @@ piece of R and of S. Per join:
   1. histogram   destination of a tuple = key & (G-1)   (HASH_BIT_MODULO on the low bits,
                  mc/src/parallel_radix_join.c:59)                     -> hj_shard_histogram_dev
   2. counts      one all_to_all_single of the G per-destination counts (R and S together)
-  3. scatter     tuples grouped by destination; an R tuple travels as (globalIndex << (32-s) | key >> s),
-                 s = log2 G: index priority survives the exchange, and the shard bits of the key --
-                 the same for every tuple of a destination -- give their room to the index, which
-                 may use 32+s bits (8 x 2^30 tuples fit)                 -> hj_shard_scatter_dev
+  3. scatter     tuples grouped by destination IN INPUT ORDER, written as bare 32-bit keys (a DataGen
+                 tuple is its key): 4 bytes per tuple cross the links            -> hj_shard_scatter_dev
   4. exchange    one all-to-all per relation, issued as a batch of direct pairwise sends/receives of at
                  most 512 MiB (async: R's exchange overlaps the split of S, S's exchange overlaps the
                  local build); every rank sends 1/G of its tuples to every peer directly, so all xGMI
-                 links carry traffic at once (no ring)
-  5. local join  open-addressing build of the received R into a table of 2*|R_local| slots by
-                 global index priority, home slot = (key >> log2 G) & mask (the shard bits are the
-                 same for every local tuple), probe with the received S
-                                                                     -> hj_build_packed_dev / hj_probe_dev
+                 links carry traffic at once (no ring). The receiver lays the pieces out in source-rank
+                 order: since rank g holds the g-th piece of the relation and the scatter keeps input
+                 order, position in the received buffer is GLOBAL input order -- the reference's
+                 insertion order survives the exchange without any index travelling
+  5. local join  open-addressing build of the received R keys into a table of 2*|R_local| slots, priority
+                 = position in the received buffer, home slot = (key >> log2 G) & mask (the shard bits
+                 are the same for every local key), probe with the received S keys
+                                                                     -> hj_build_keys_dev / hj_probe_keys_dev
   6. counters    one all_reduce(sum) of {conflicts, matches, sums}
 
 Result semantics: shard g's table holds the tuples whose low key bits are g, inserted in GLOBAL
@@ -26,8 +27,8 @@ input order with the reference's probe budget; the test suite restates exactly t
 compares bit-exactly (tests/test_sharded_gloo.py). For G = 1 this is the single-GPU operator. For unique keys
 (sorted / shuffle / local_shuffle) the totals equal the single-table result (conflicts 0,
 matches |R|); for duplicate keys they are the radix-partitioned variant of it, a different but
-equally deterministic number (linear-probe neighbourhoods differ once the table is split). Sizes: total
-|R| < 2^(32 + log2 G), 2^31 per rank.
+equally deterministic number (linear-probe neighbourhoods differ once the table is split). Sizes:
+2^31 tuples per rank and relation, at most 2^32 received per rank.
 
 The compute engine is injected: HipShardEngine (below) is the product path and the only engine in
 this package; the CPU tests inject a checker-backed engine of their own to exercise this file's
@@ -59,18 +60,18 @@ class HipShardEngine:
     def close(self):
         self.ctx.close()
 
-    def empty(self, n):
-        return self.torch.empty(max(int(n), 1), dtype=self.torch.int64, device=self.dev)[: int(n)]
+    def empty_keys(self, n):
+        """buffer of n 32-bit keys (int32 holds the bit pattern; +4 elements so 16-byte sweeps stay inside)"""
+        return self.torch.empty(int(n) + 4, dtype=self.torch.int32, device=self.dev)[: int(n)]
 
     def histogram(self, t, n_shards):
         counts = self.torch.zeros(n_shards, dtype=self.torch.int64, device=self.dev)
-        self.ctx.shard_histogram(t.data_ptr(), t.numel(), n_shards, 0, 0, counts.data_ptr())
+        self.ctx.shard_histogram(t.data_ptr(), t.numel(), n_shards, counts.data_ptr())
         return counts
 
-    def scatter(self, t, n_shards, counts, pack_idx_base, strip_bits):
-        out = self.empty(t.numel())
-        self.ctx.shard_scatter(t.data_ptr(), t.numel(), n_shards, 0, 0, counts.data_ptr(), pack_idx_base,
-                               strip_bits, out.data_ptr())
+    def scatter(self, t, n_shards, counts):
+        out = self.empty_keys(t.numel())
+        self.ctx.shard_scatter(t.data_ptr(), t.numel(), n_shards, counts.data_ptr(), out.data_ptr())
         return out
 
     def reserve(self, table_size, max_r, max_s):
@@ -84,17 +85,17 @@ class HipShardEngine:
             self.ctx.reserve("atomic", r, max_s, buildVariant=self.build_variant)
             self._reserved = key
 
-    def build(self, r_packed, strip_bits, shard_id, table_size):
-        self.ctx.build_packed(r_packed.data_ptr(), r_packed.numel(), strip_bits, shard_id, table_size)
+    def build(self, r_keys, home_shift, table_size):
+        self.ctx.build_keys(r_keys.data_ptr(), r_keys.numel(), home_shift, table_size)
 
     def probe(self, s_keys):
-        self.ctx.probe(s_keys.data_ptr(), s_keys.numel())
+        self.ctx.probe_keys(s_keys.data_ptr(), s_keys.numel())
 
     def finish(self):
         self.ctx.checksums()
         r = self.ctx.fetch()
         return {k: r[k] for k in ("conflicts", "totalMatches", "inputSum", "tableSumFull", "conflictSum",
-                                  "buildVariant", "buildDeferred", "build_us", "probe_us", "clear_us")}
+                                  "buildVariant", "buildDeferred", "build_us", "probe_us", "clear_us", "buildPhaseA_us")}
 
     def sync(self):
         self.torch.cuda.synchronize(self.dev)
@@ -105,8 +106,9 @@ class ShardedJoin:
 
     def __init__(self, engine, torch, dist, rank, world):
         self.e, self.torch, self.dist, self.rank, self.world = engine, torch, dist, rank, world
-        self.strip = _log2(world)       # shard bits stripped from the keys of the local tables
+        self.shift = _log2(world)       # shard bits, shifted out of the home slot in the local tables
         self.last = {}
+        self._keep = None
 
     def _exchange_counts(self, cnt_r, cnt_s):
         both = self.torch.cat([cnt_r, cnt_s]).reshape(2, self.world).t().contiguous()   # [dest][R,S]
@@ -119,17 +121,17 @@ class ShardedJoin:
         got = recv.cpu().tolist()
         return [s[0] for s in send], [s[1] for s in send], [g[0] for g in got], [g[1] for g in got]
 
-    # Largest single message, in tuples. RCCL (ROCm 7.0 wheel of torch 2.10) delivered only half of an
+    # Largest single message, in keys. RCCL (ROCm 7.0 wheel of torch 2.10) delivered only half of an
     # all_to_all_single whose per-peer message reached 2 GiB (tools/dbg/a2a_check.py: 2^27 int64 fine, 2^28
     # half missing), so the exchange is issued as point-to-point messages of at most 512 MiB.
-    max_msg_tuples = 1 << 26
+    max_msg_tuples = 1 << 27
 
     def _exchange_async(self, send, send_counts, recv_counts):
         """Starts the exchange of one relation: direct pairwise sends (every peer at once, so all xGMI links
         carry traffic; no ring), batched into one group. Returns (output tensor, work handles). With NCCL/RCCL
         the transfers run on the backend's stream behind the kernels already enqueued on the current stream,
         and work.wait() only makes the current stream wait (no host block)."""
-        out = self.e.empty(sum(recv_counts))
+        out = self.e.empty_keys(sum(recv_counts))
         so = [0]
         for c in send_counts:
             so.append(so[-1] + c)
@@ -154,21 +156,25 @@ class ShardedJoin:
                 works = self.dist.batch_isend_irecv(ops)
         return out, works
 
-    def step(self, r_local, s_local, idx_base, table_size):
-        """One build+probe over this rank's shards. Everything is enqueued; call result() to sync.
-        The exchange of R overlaps the split of S, and the exchange of S overlaps the local build."""
+    def step(self, r_local, s_local, table_size):
+        """One build+probe over this rank's pieces (rank g holds the g-th contiguous piece of each relation).
+        Everything is enqueued; call result() to sync. The exchange of R overlaps the split of S, and the
+        exchange of S overlaps the local build."""
         e = self.e
+        # the previous step's buffers go back to the allocator first (its kernels precede ours in stream order, its
+        # transfers are done -- we waited on them): every step after the first reuses the same blocks, no hipMalloc
+        self._keep = None
         cnt_r = e.histogram(r_local, self.world)
         cnt_s = e.histogram(s_local, self.world)
         send_r, send_s, recv_r, recv_s = self._exchange_counts(cnt_r, cnt_s)
-        out_r = e.scatter(r_local, self.world, cnt_r, idx_base, self.strip)     # (gidx << (32-s) | key >> s)
+        out_r = e.scatter(r_local, self.world, cnt_r)                           # keys, grouped by destination
         got_r, work_r = self._exchange_async(out_r, send_r, recv_r)
-        out_s = e.scatter(s_local, self.world, cnt_s, None, 0)                  # unchanged tuples
+        out_s = e.scatter(s_local, self.world, cnt_s)
         got_s, work_s = self._exchange_async(out_s, send_s, recv_s)
         e.reserve(table_size, got_r.numel(), got_s.numel())
         for w in work_r:
             w.wait()
-        e.build(got_r, self.strip, self.rank, table_size)
+        e.build(got_r, self.shift, table_size)
         for w in work_s:
             w.wait()
         e.probe(got_s)
@@ -188,6 +194,20 @@ class ShardedJoin:
         out["local"] = r
         out["exchange"] = dict(self.last)
         return out
+
+
+def _local_roofline(res):
+    """Roofline of the dominant LOCAL kernel on rank 0 in the last step (the exchange is xGMI-bound and reported
+    beside it as ms_per_step - local kernels): k_build_own over the received keys, 4 B read + 8 B slot written per
+    R tuple; only when the LDS-window build ran."""
+    loc, ex = res["local"], res["exchange"]
+    if loc["buildVariant"] != 2 or not loc["buildPhaseA_us"]:
+        return None
+    nbytes = 12.0 * ex["recv_r"]
+    gbps = nbytes / (loc["buildPhaseA_us"] * 1e-6) / 1e9
+    return {"bound": "hbm", "kernel": "k_build_own<keys> (rank 0, last step)", "achieved": gbps, "peak": 8000.0,
+            "unit": "GB/s", "frac": gbps / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": nbytes,
+            "launch_us": loc["buildPhaseA_us"]}
 
 
 def bench_sharded(args, torch, dist, hj, rank, world, local_rank):
@@ -212,7 +232,7 @@ def bench_sharded(args, torch, dist, hj, rank, world, local_rank):
     table_size = 2 * n
 
     def step():
-        job.step(r_local, s_local, rank * n, table_size)
+        job.step(r_local, s_local, table_size)
 
     for _ in range(args.warmup):
         step()
@@ -238,7 +258,7 @@ def bench_sharded(args, torch, dist, hj, rank, world, local_rank):
         "data": "synthetic (DataGen restatement per rank on its own key range)",
         "config": {"workload": f"radix-sharded open-addressing build+probe over {world} GPUs, |R|=|S|={n} per GPU "
                                f"({n * world} in total), dataDistr={args.dist} W={window}; step = destination histogram + "
-                               "order-preserving scatter + all-to-all (R and S, overlapped) + local table build/probe",
+                               "order-preserving scatter to 32-bit keys + all-to-all (R and S, overlapped) + local table build/probe",
                    "algo": "atomic", "rSize": n * world,
                    "sSize": n * world, "per_gpu_rSize": n, "dataDistr": args.dist, "shuffleRange": window,
                    "parallelism": f"radix{world}"},
@@ -248,7 +268,7 @@ def bench_sharded(args, torch, dist, hj, rank, world, local_rank):
                    "tableSum_plus_conflictSum_eq_inputSum": res["tableSumFull"] + res["conflictSum"] == res["inputSum"]},
         "exchange": res["exchange"], "local_kernel_us": {k: res["local"][k] for k in ("clear_us", "build_us", "probe_us")},
         "local_build_variant": res["local"]["buildVariant"],
-        "roofline": None, "cpu_baseline": None,
+        "roofline": _local_roofline(res), "cpu_baseline": None,
     }
     eng.close()
     return line

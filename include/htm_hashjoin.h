@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HJ_ABI_VERSION 1
+#define HJ_ABI_VERSION 2
 
 typedef enum {
     HJ_OK                  = 0,
@@ -170,36 +170,33 @@ int hj_export_table(hj_ctx *ctx, uint64_t *host_table, uint64_t tableSize);
 
 /* ---- multi-GPU sharding helpers (new design) ---------------- */
 /* dest(key) = key & (nShards-1): the low key bits (HASH_BIT_MODULO,
- * parallel_radix_join.c:59); nShards a power of two <= 64. `mode` must be 0 and
- * `tableSize` is ignored (reserved for a range split). */
+ * parallel_radix_join.c:59); nShards a power of two <= 64. `mode` must be 0
+ * (reserved for a range split). */
 /* Counts tuples per destination into dCounts[nShards] (device, uint64) and keeps
  * the per-chunk write cursors for the scatter of the same input. Async. */
 int hj_shard_histogram_dev(hj_ctx *ctx, const uint64_t *dIn, uint64_t n,
-                           uint32_t nShards, uint32_t mode, uint64_t tableSize,
-                           uint64_t *dCounts);
-/* Scatter of dIn into dOut (both n tuples) grouped by destination; must follow
- * hj_shard_histogram_dev on the same (dIn, n). The input order is preserved
- * chunk-wise inside every destination (scan-based cursors; only the 4096 tuples
- * of a tile may be permuted among themselves), so near-sorted inputs stay
- * near-sorted. With packIdxBase == UINT64_MAX tuples are copied unchanged
- * (stripBits ignored). Otherwise each output tuple is
- *     ((packIdxBase + i) << (32 - stripBits)) | (key >> stripBits):
- * the tuple's global input index travels with it so that index priority
- * survives the exchange, and the low stripBits key bits -- the shard number,
- * identical for every tuple of a destination -- give their room to the index,
- * which may therefore use 32 + stripBits bits (8 GPUs x 2^30 tuples fit). Async. */
+                           uint32_t nShards, uint32_t mode, uint64_t *dCounts);
+/* Scatter of the n tuples of dIn, grouped by destination, into dOutKeys as bare
+ * 32-bit keys (a DataGen tuple is its key, DataGen.hpp:29: the exchange then
+ * moves 4 bytes per tuple instead of 8). Must follow hj_shard_histogram_dev on
+ * the same (dIn, n). The input order is preserved inside every destination
+ * (scan-based cursors, no atomics across workgroups). That is what carries the
+ * reference's insertion order through the exchange: when rank g holds the g-th
+ * contiguous piece of the relation and the receiver lays the pieces out in rank
+ * order, position in the received buffer IS global input order, so no index
+ * has to travel. Async. */
 int hj_shard_scatter_dev(hj_ctx *ctx, const uint64_t *dIn, uint64_t n,
-                         uint32_t nShards, uint32_t mode, uint64_t tableSize,
-                         const uint64_t *dCounts, uint64_t packIdxBase,
-                         uint32_t stripBits, uint64_t *dOut);
-/* Like hj_build_dev for tuples in the packed format above (the output of
- * hj_shard_scatter_dev after the exchange), into a table of tableSize slots (a
- * power of two, reserved via hj_reserve(rSize = tableSize/2)). shardId is the
- * value of the stripped key bits (this rank's number); the home slot of a key
- * is (key >> stripBits) & (tableSize-1). hj_probe_dev afterwards takes plain
- * tuples (value = key) whose low stripBits bits equal shardId. */
-int hj_build_packed_dev(hj_ctx *ctx, const uint64_t *dPacked, uint64_t n,
-                        uint32_t stripBits, uint32_t shardId, uint64_t tableSize);
+                         uint32_t nShards, uint32_t mode,
+                         const uint64_t *dCounts, uint32_t *dOutKeys);
+/* hj_build_dev / hj_probe_dev for bare keys (the received side of the exchange):
+ * tuple i of dKeys has index i; table of tableSize slots (a power of two,
+ * reserved via hj_reserve(rSize = tableSize/2)); home slot of a key =
+ * (key >> homeShift) & (tableSize-1) with homeShift = log2(nShards): inside a
+ * shard the low key bits are the same for every key and would leave all but
+ * every nShards-th slot unused. */
+int hj_build_keys_dev(hj_ctx *ctx, const uint32_t *dKeys, uint64_t n,
+                      uint32_t homeShift, uint64_t tableSize);
+int hj_probe_keys_dev(hj_ctx *ctx, const uint32_t *dKeys, uint64_t n);
 
 /* ---- device memory for hosts without a HIP runtime of their own ----------- */
 int hj_dev_alloc(hj_ctx *ctx, uint64_t bytes, void **dptr);

@@ -274,70 +274,90 @@ def test_config2_size_properties(ctx):
 
 
 # ---- radix-sharded path: every GPU kernel of htm_hashjoin_amd/sharded.py on one device ------------
-@pytest.mark.parametrize("G", [2, 8])
+@pytest.mark.parametrize("G", [2, 8, 64])
 @pytest.mark.parametrize("dist,window", [("uniform", 16), ("local_shuffle", 1024), ("random", 16)])
 @pytest.mark.parametrize("variant", [1, 2])
 def test_sharded_kernels_on_one_gpu(ctx, G, dist, window, variant):
-    """G ranks emulated in turn on one GPU: shard histogram + scatter (index packing) per source piece,
-    the all-to-all done on the host, then hj_build_packed_dev / hj_probe_dev per destination shard.
-    Totals must equal oracle.sharded_reference (sequential, global input order, per-shard tables)."""
+    """G ranks emulated in turn on one GPU: shard histogram + STABLE scatter to 32-bit keys per source piece, the
+    all-to-all done on the host (pieces laid out in source-rank order), then hj_build_keys_dev / hj_probe_keys_dev per
+    destination shard. The scatter must equal numpy's stable sort by destination element for element; totals and every
+    shard's table must equal the sequential oracle on the shard's tuples in global input order."""
+    if G == 64 and (variant == 1 or dist == "random"):
+        pytest.skip("G = 64 is covered once per build kernel input")
     n = 1 << 16
     n_local = n // G
+    n_piece = n_local + 3 if G == 2 else n_local          # ragged pieces too (the last one is shorter)
     R = oracle.generate_data(dist, n, n, window)
     S = oracle.relS_for(dist, R)
-    want = oracle.sharded_reference(R, S, G)
-    strip = G.bit_length() - 1
-    # index base beyond 32 bits when the format allows it (strip >= 1): the 8 x 2^30 case needs 33 bits
-    BASE = (1 << 32) + 12345 if strip >= 1 else 0
+    shift = G.bit_length() - 1
     inbox_r = [[] for _ in range(G)]
     inbox_s = [[] for _ in range(G)]
     with hj.HashJoinContext(0) as c:
-        d_in = c.dev_alloc(n_local * 8); d_out = c.dev_alloc(n_local * 8); d_cnt = c.dev_alloc(G * 8)
+        d_in = c.dev_alloc((n_piece + 1) * 8); d_out = c.dev_alloc((n_piece + 4) * 4); d_cnt = c.dev_alloc(G * 8)
         for src in range(G):
-            for rel, inbox, base in ((R, inbox_r, BASE + src * n_local), (S, inbox_s, None)):
-                piece = rel[src * n_local:(src + 1) * n_local]
+            for rel, inbox in ((R, inbox_r), (S, inbox_s)):
+                piece = rel[src * n_piece:(src + 1) * n_piece]
+                m = piece.size
                 c.copy_h2d(d_in, piece)
-                c.shard_histogram(d_in, n_local, G, 0, 0, d_cnt)
-                c.shard_scatter(d_in, n_local, G, 0, 0, d_cnt, base, strip if base is not None else 0, d_out)
+                c.shard_histogram(d_in, m, G, d_cnt)
+                c.shard_scatter(d_in, m, G, d_cnt, d_out)
                 cnt = np.empty(G, dtype=np.uint64); c.copy_d2h(cnt, d_cnt)
-                out = np.empty(n_local, dtype=np.uint64); c.copy_d2h(out, d_out)
-                assert np.array_equal(cnt, np.bincount((piece & np.uint64(G - 1)).astype(np.int64), minlength=G).astype(np.uint64))
+                out = np.empty(m, dtype=np.uint32); c.copy_d2h(out, d_out)
+                dest = (piece & np.uint64(G - 1)).astype(np.int64)
+                assert np.array_equal(cnt, np.bincount(dest, minlength=G).astype(np.uint64))
+                assert np.array_equal(out, piece[np.argsort(dest, kind="stable")].astype(np.uint32))     # stable, element for element
                 off = 0
                 for g in range(G):
-                    seg = out[off:off + int(cnt[g])]; off += int(cnt[g])
-                    if base is None:
-                        assert np.all((seg & np.uint64(G - 1)) == g)               # grouped by destination, unchanged
-                    else:                                                          # index packed above the stripped key
-                        idx = (seg >> np.uint64(32 - strip)).astype(np.int64)
-                        sel = np.nonzero((piece & np.uint64(G - 1)) == g)[0]
-                        assert np.array_equal(np.sort(idx), base + sel)
-                        keyp = seg & np.uint64(0xFFFFFFFF >> strip)
-                        assert np.array_equal(np.sort((keyp << np.uint64(strip)) | np.uint64(g)), np.sort(piece[sel]))
-                        # input order is preserved up to permutations inside one 4096-tuple tile
-                        if idx.size:
-                            assert np.all(idx - np.maximum.accumulate(idx) > -4096)
-                    inbox[g].append(seg)
+                    inbox[g].append(out[off:off + int(cnt[g])]); off += int(cnt[g])
         for p in (d_in, d_out, d_cnt):
             c.dev_free(p)
     tot = {k: 0 for k in ("conflicts", "totalMatches", "inputSum", "tableSumFull", "conflictSum")}
     table_size = 2 * n_local
     for g in range(G):
         got_r = np.concatenate(inbox_r[g]); got_s = np.concatenate(inbox_s[g])
+        assert np.array_equal(got_r, R[(R & np.uint64(G - 1)) == g].astype(np.uint32))       # global input order
+        want = oracle.build_probe_seq_ts(got_r.astype(np.uint64), got_s.astype(np.uint64), table_size, shift, want_table=True)
         with hj.HashJoinContext(0) as c:
             r = table_size // 2
             while r < got_r.size:
                 r *= 2
             c.reserve("atomic", r, got_s.size, buildVariant=variant)
-            d_r = c.dev_alloc(max(got_r.size, 1) * 8); d_s = c.dev_alloc(max(got_s.size, 1) * 8)
-            c.copy_h2d(d_r, got_r); c.copy_h2d(d_s, got_s)
-            c.build_packed(d_r, got_r.size, strip, g, table_size)
-            c.probe(d_s, got_s.size)
+            # odd offsets: the key buffers of an exchange start wherever the previous peer's keys ended
+            d_r = c.dev_alloc((got_r.size + 8) * 4); d_s = c.dev_alloc((got_s.size + 8) * 4)
+            c.copy_h2d(d_r + 4, got_r) if got_r.size else None
+            c.copy_h2d(d_s + 12, got_s) if got_s.size else None
+            c.build_keys(d_r + 4, got_r.size, shift, table_size)
+            c.probe_keys(d_s + 12, got_s.size)
             c.checksums()
             res = c.fetch()
+            if table_size >= 8192:
+                assert res["buildVariant"] == variant
             for k in tot:
+                assert res[k] == want[k], (g, k)
                 tot[k] += res[k]
+            assert np.array_equal(c.export_table(table_size), want["table"])
             c.dev_free(d_r); c.dev_free(d_s)
-    assert tot == want
+    assert tot == oracle.sharded_reference(R, S, G)
+
+
+def test_shard_split_flags_payload_bits(ctx):
+    """A tuple with payload bits set cannot be told from a valid one once only keys travel: the split sends it as
+    key 0 (to shard 0), where the build reports it like hj_build_dev does (HJ_ERR_KEY_RANGE)."""
+    n, G = 1 << 13, 4
+    R = oracle.generate_data("sorted", n)
+    R[1234] |= np.uint64(1) << np.uint64(40)
+    with hj.HashJoinContext(0) as c:
+        d_in = c.dev_alloc(n * 8); d_out = c.dev_alloc(n * 4); d_cnt = c.dev_alloc(G * 8)
+        c.copy_h2d(d_in, R)
+        c.shard_histogram(d_in, n, G, d_cnt)
+        c.shard_scatter(d_in, n, G, d_cnt, d_out)
+        cnt = np.empty(G, dtype=np.uint64); c.copy_d2h(cnt, d_cnt)
+        assert cnt.tolist() == [n // G + 1, n // G, n // G, n // G - 1]       # key 1235 (low bits 3) went to shard 0 as key 0
+        c.reserve("atomic", n // G * 2, 0)
+        c.build_keys(d_out, int(cnt[0]), 2, 2 * (n // G) * 2)
+        with pytest.raises(hj.HashJoinError) as e:
+            c.fetch()
+        assert e.value.status == hj.HJ_ERR_KEY_RANGE
 
 
 def test_skew_probe_side_zipf(ctx):

@@ -20,44 +20,35 @@ class OracleShardEngine:
     def __init__(self):
         self._res = None
 
-    def empty(self, n):
-        return torch.empty(int(n), dtype=torch.int64)
+    def empty_keys(self, n):
+        return torch.empty(int(n), dtype=torch.int32)
 
     def histogram(self, t, n_shards):
         k = t.numpy().view(np.uint64)
         return torch.from_numpy(np.bincount((k & np.uint64(n_shards - 1)).astype(np.int64), minlength=n_shards)).to(torch.int64)
 
-    def scatter(self, t, n_shards, counts, pack_idx_base, strip_bits):
+    def scatter(self, t, n_shards, counts):
+        """grouped by destination, input order kept inside each (what hj_shard_scatter_dev guarantees), keys only"""
         k = t.numpy().view(np.uint64)
         dest = (k & np.uint64(n_shards - 1)).astype(np.int64)
-        order = np.argsort(dest, kind="stable")[::1]
-        rng = np.random.default_rng(len(k))            # the product's order inside a destination is undefined:
-        for d in range(n_shards):                      # shuffle inside each destination to prove it does not matter
-            seg = np.nonzero(dest[order] == d)[0]
-            order[seg] = rng.permutation(order[seg])
-        kp = k.copy()
-        if pack_idx_base is not None:
-            idx = np.arange(len(k), dtype=np.uint64) + np.uint64(pack_idx_base)
-            kp = (idx << np.uint64(32 - strip_bits)) | (k >> np.uint64(strip_bits))
-        return torch.from_numpy(kp[order].view(np.int64).copy())
+        order = np.argsort(dest, kind="stable")
+        return torch.from_numpy(k[order].astype(np.uint32).view(np.int32).copy())
 
     def reserve(self, table_size, max_r, max_s):
         pass
 
-    def build(self, r_packed, strip_bits, shard_id, table_size):
-        p = r_packed.numpy().view(np.uint64)
-        p = np.sort(p)                                  # global index is the high field: sort = global input order
-        keys = ((p & np.uint64(0xFFFFFFFF >> strip_bits)) << np.uint64(strip_bits)) | np.uint64(shard_id)
-        self._built = (keys, strip_bits, table_size)
+    def build(self, r_keys, home_shift, table_size):
+        # position in the receive buffer = insertion order
+        self._built = (r_keys.numpy().view(np.uint32).astype(np.uint64), home_shift, table_size)
 
     def probe(self, s_keys):
         keys, home_shift, table_size = self._built
-        s = s_keys.numpy().view(np.uint64)
+        s = s_keys.numpy().view(np.uint32).astype(np.uint64)
         self._res = oracle.build_probe_seq_ts(keys, s, table_size, home_shift)
 
     def finish(self):
         r = dict(self._res)
-        r.update(buildVariant=0, buildDeferred=0, build_us=0.0, probe_us=0.0, clear_us=0.0)
+        r.update(buildVariant=0, buildDeferred=0, build_us=0.0, probe_us=0.0, clear_us=0.0, buildPhaseA_us=0.0)
         return r
 
     def sync(self):
@@ -68,7 +59,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, dist_name, window, n_local, out, idx_offset=0):
+def _worker(rank, world, port, dist_name, window, n_local, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import htm_hashjoin_amd as hj
@@ -80,7 +71,7 @@ def _worker(rank, world, port, dist_name, window, n_local, out, idx_offset=0):
     s_local = torch.from_numpy(S[rank * n_local:(rank + 1) * n_local].view(np.int64).copy())
     job = ShardedJoin(OracleShardEngine(), torch, dist, rank, world)
     job.max_msg_tuples = 700            # force the exchange into several messages per peer
-    job.step(r_local, s_local, idx_offset + rank * n_local, 2 * n_local)
+    job.step(r_local, s_local, 2 * n_local)
     res = job.result()
     if rank == 0:
         out.put({k: res[k] for k in ("conflicts", "totalMatches", "inputSum", "tableSumFull", "conflictSum")})
@@ -93,9 +84,7 @@ def test_sharded_join_matches_sharded_reference(world, dist_name, window):
     n_local = 1 << 12
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    # global indices beyond 32 bits (what 8 GPUs x 2^30 tuples need) whenever the packed format has room
-    idx_offset = (1 << 32) + 7 if dist_name == "uniform" else 0
-    procs = [ctx.Process(target=_worker, args=(r, world, PORT[0], dist_name, window, n_local, q, idx_offset))
+    procs = [ctx.Process(target=_worker, args=(r, world, PORT[0], dist_name, window, n_local, q))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -122,13 +111,13 @@ def _port():
 
 
 def test_single_rank_is_the_plain_operator():
-    """world == 1: no exchange, no stripped bits; totals equal the single-table oracle."""
+    """world == 1: no exchange, no home shift; totals equal the single-table oracle."""
     from htm_hashjoin_amd.sharded import ShardedJoin
     n = 1 << 12
     R = oracle.generate_data("uniform", n, n, 16)
     S = oracle.generate_data("sorted", n)
     job = ShardedJoin(OracleShardEngine(), torch, None, 0, 1)
-    job.step(torch.from_numpy(R.view(np.int64).copy()), torch.from_numpy(S.view(np.int64).copy()), 0, 2 * n)
+    job.step(torch.from_numpy(R.view(np.int64).copy()), torch.from_numpy(S.view(np.int64).copy()), 2 * n)
     got = job.result()
     want = oracle.build_probe_seq(R, S)
     for k in ("conflicts", "totalMatches", "inputSum", "tableSumFull", "conflictSum"):
