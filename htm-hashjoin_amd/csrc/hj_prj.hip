@@ -765,19 +765,19 @@ void launch_prj(const PrjPlan& pl, const PrjBuffers& buf, const uint64_t* R, uin
 // not care). It also keeps a near-sorted input near-sorted, so the receiver's locality pre-round still
 // picks the LDS-window build.
 //
-// Ranking without atomics: lane l of wavefront w holds, for k = 0..15, the tile's element k*512 + 64 w + l,
+// Ranking without atomics: lane l of wavefront w holds, for k = 0..7, the tile's element k*1024 + 64 w + l,
 // so (k, w, l) is input order. For one k a wavefront finds, per lane, the lanes with the same
 // destination (log2(fan) ballots) -- its rank among them is a popcount of the lower lanes, their
 // number goes to cnt[bin][k][w]. An exclusive scan of cnt in exactly that order gives every
 // (bin, k, w) group its place in the tile's staged order.
 // ---------------------------------------------------------------------------
-constexpr int kStabThreads = 512;
-constexpr int kStabPer = 16;                                   // tuples per thread per tile
+constexpr int kStabThreads = 1024;
+constexpr int kStabPer = 8;                                    // tuples per thread per tile
 constexpr int kStabTile = kStabThreads * kStabPer;             // 8192
 constexpr int kStabGroups = kStabPer * (kStabThreads / 64);    // (k, wavefront) groups per tile = 128
 constexpr int kStabMaxFan = 64;
 
-__global__ void __launch_bounds__(kStabThreads, 4)
+__global__ void __launch_bounds__(kStabThreads, 8)
 k_shard_scatter_stable(const uint64_t* __restrict__ in, uint32_t* __restrict__ out, PassParams p,
                        const uint32_t* __restrict__ scanned)
 {
@@ -799,8 +799,8 @@ k_shard_scatter_stable(const uint64_t* __restrict__ in, uint32_t* __restrict__ o
     int bits = 0;
     while ((1u << bits) < p.fan) ++bits;
     if (threadIdx.x < p.fan) cursor[threadIdx.x] = scanned[hist_index(p, r, threadIdx.x)];
-    const uint32_t perThread = nCnt / kStabThreads;               // fan * 128 / 512 = fan / 4 (fan >= 4) ...
-    const uint32_t items = perThread ? perThread : 1;             // ... or 1 with some threads idle (fan < 4)
+    const uint32_t perThread = nCnt / kStabThreads;               // fan * 128 / 1024 = fan / 8 (fan >= 8) ...
+    const uint32_t items = perThread ? perThread : 1;             // ... or 1 with some threads idle (fan < 8)
     __syncthreads();
 
     for (uint32_t tb = 0; tb < len; tb += kStabTile) {

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """BASELINE config 5: skew stress, |R| = 2^28 unique keys, |S| = 4 x 2^30 probes drawn Zipf(0.9) over R's key domain
-(mc/src/genzipf.c method; the 2^30-tuple sample is probed four times: 4.29 G probes), 1 GPU. R unique => every probe
+(mc/src/genzipf.c method; a 2^log2s-tuple sample is probed `reps` times: 2^28 x 16 = 4.29 G probes), 1 GPU. R unique => every probe
 finds exactly one tuple: totalMatches must equal the number of probes. One JSON line per algorithm.
-usage: python tools/skew_config5.py [--log2r 28] [--log2s 30] [--reps 4] [--rdist local_shuffle --window 1024]"""
+usage: python tools/skew_config5.py [--log2r 28] [--log2s 28] [--reps 16] [--rdist local_shuffle --window 1024]"""
 import argparse
 import json
 import os
@@ -16,16 +16,24 @@ import htm_hashjoin_amd as hj
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log2r", type=int, default=28)
-    ap.add_argument("--log2s", type=int, default=30)
-    ap.add_argument("--reps", type=int, default=4, help="the S sample is probed this many times")
+    ap.add_argument("--log2s", type=int, default=28)
+    ap.add_argument("--reps", type=int, default=16, help="the S sample is probed this many times")
     ap.add_argument("--theta", type=float, default=0.9)
     ap.add_argument("--rdist", default="local_shuffle")
     ap.add_argument("--window", type=int, default=1024)
     a = ap.parse_args()
     nr, ns = 1 << a.log2r, 1 << a.log2s
     t0 = time.time()
+    import threading
+    stop = threading.Event()
+
+    def beat():                       # serial libc rand() streams take minutes at this size: show signs of life
+        while not stop.wait(60):
+            print(f"... generating, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
+    threading.Thread(target=beat, daemon=True).start()
     R = hj.generate_data(a.rdist, nr, nr, a.window)
     S = hj.generate_data("zipf", ns, nr, 16, zipf_theta=a.theta)
+    stop.set()
     print(json.dumps({"datagen_s": round(time.time() - t0, 1), "rSize": nr, "sSize": ns, "theta": a.theta}), flush=True)
     with hj.HashJoinContext(0) as ctx:
         dR = ctx.dev_alloc(nr * 8); dS = ctx.dev_alloc(ns * 8)
