@@ -3,6 +3,8 @@
 // drain every 8 steps like the kernel. usage: retry <file of u64 tuples> <n> <scheme>
 //   scheme 0: fast step = one atomicMin at the home slot (the kernel as it is)
 //   scheme 1: a lane starts at home + (number of earlier lanes of the step with the same home), drops at once if that is >= 4
+//   scheme 2 / 3: the same, but only lanes whose home lies in [base, base + 64) / [base, base + 128) take part,
+//                 base = home of lane 0 - 16 / - 48 (what a per-wavefront LDS bitmask table of that size can resolve)
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -47,6 +49,10 @@ int main(int argc, char **argv)
             uint64_t i = b + l, mine = (i << 32) | R[i], pos = R[i] & mask;
             int r = 0;
             if (scheme == 1) for (int k = 0; k < l; k++) r += (R[b + k] & mask) == (R[i] & mask);
+            if (scheme >= 2) {
+                const uint64_t span = scheme == 2 ? 64 : 128, base = (R[b] & mask) - (scheme == 2 ? 16 : 48);
+                if (((R[i] & mask) - base) < span) for (int k = 0; k < l; k++) r += (R[b + k] & mask) == (R[i] & mask);
+            }
             if (r >= PL) { drops++; continue; }
             int before = qn;
             attempt(mine, (pos + r) & mask);
