@@ -213,20 +213,31 @@ def _local_roofline(res):
 def bench_sharded(args, torch, dist, hj, rank, world, local_rank):
     """bench.py's N > 1 leg. Default = WEAK scaling: every rank holds 2^log2n tuples of R and of S (the N=1
     workload per GPU; 8 GPUs x 2^30 = BASELINE config 4); --strong keeps the N=1 total and splits it.
-    Rank g's piece = DataGen over its own key range (g*n, (g+1)*n]: globally the near-sorted relation the
-    reference generates, drawn piecewise (a rank cannot afford the serial rand() stream of its
-    neighbours). Keys are 32 bits, so once the global range passes 2^32 - 1 it wraps (keys then repeat across
-    ranks, which the operator handles like any duplicate key)."""
+    Globally the relation is the near-sorted one the reference generates, cut into contiguous pieces: rank g's
+    piece = DataGen over its own key range, drawn piecewise (a rank cannot afford the serial rand() stream of its
+    neighbours). Keys are 32 bits: while world * n <= 2^32 - 1 rank g owns the keys (g*n, (g+1)*n]; beyond that
+    (8 x 2^30 tuples, 2^32 keys) the key domain is still cut into `world` contiguous ranges and a rank's n draws
+    are squeezed into its range -- every key about world*n / 2^32 times, duplicates adjacent, as in a globally
+    sorted relation with more tuples than keys."""
     strip = _log2(world)
     n = (1 << args.log2n) >> (strip if args.strong else 0)          # tuples per rank and relation
     window = args.shuffle_range
     wrap = (1 << 32) - 1
-    R = hj.generate_data(args.dist, n, n, window)
-    R = ((R + np.uint64(rank * n) - np.uint64(1)) % np.uint64(wrap)) + np.uint64(1)
-    r_local = torch.from_numpy(R.view("int64")).to(f"cuda:{local_rank}")
-    del R
-    s_local = torch.arange(rank * n, (rank + 1) * n, dtype=torch.int64, device=f"cuda:{local_rank}")
-    s_local = torch.remainder(s_local, wrap) + 1                     # generate_data("sorted") on the same key range
+    width = min(n, wrap // world)                                    # keys in a rank's range
+    R = hj.generate_data(args.dist, n, n, window)                    # values in [1, n] (uniform and the unique-key kinds)
+
+    def to_range(v):                                                 # [1, n] -> (rank*width, (rank+1)*width], order kept
+        if args.dist == "random":                                    # 31-bit random keys: no range to speak of
+            return v
+        v = v - np.uint64(1)
+        if width != n:
+            v = (v * np.uint64(width)) // np.uint64(n)
+        return v + np.uint64(rank * width + 1)
+    r_local = torch.from_numpy(to_range(R).view("int64")).to(f"cuda:{local_rank}")
+    # S as main.cpp:91-97 builds it: sorted 1..N on the same key range (for `random`: R itself)
+    S = R.copy() if args.dist == "random" else to_range(np.arange(1, n + 1, dtype=np.uint64))
+    s_local = torch.from_numpy(S.view("int64")).to(f"cuda:{local_rank}")
+    del R, S
     eng = HipShardEngine(hj, torch, local_rank, build_variant=args.build_variant)
     job = ShardedJoin(eng, torch, dist, rank, world)
     table_size = 2 * n
@@ -247,7 +258,7 @@ def bench_sharded(args, torch, dist, hj, rank, world, local_rank):
     dt = float(t.item())
     res = job.result()
     total = 2 * n * world
-    unique_domain = n * world <= wrap
+    unique_domain = width == n
     unique = unique_domain and args.dist in ("sorted", "shuffle", "local_shuffle")
     line = {
         "metric": "Mtuples/sec build+probe, |R|=|S|=1B uint32, uniform vs local_shuffle",
