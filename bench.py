@@ -176,8 +176,18 @@ def main():
         from htm_hashjoin_amd import sharded
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist_mod.init_process_group("nccl", rank=rank, world_size=world)
-        line = sharded.bench_sharded(a, torch, dist_mod, hj, rank, world, local_rank)
+        # RCCL prints a version banner on STDOUT when the first communicator comes up; the contract is one JSON
+        # line there, so fd 1 points at stderr until the line is ready
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist_mod.init_process_group("nccl", rank=rank, world_size=world)
+            line = sharded.bench_sharded(a, torch, dist_mod, hj, rank, world, local_rank)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
         if rank == 0:
             print(json.dumps(line), flush=True)
         dist_mod.destroy_process_group()
