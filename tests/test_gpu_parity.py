@@ -340,6 +340,31 @@ def test_sharded_kernels_on_one_gpu(ctx, G, dist, window, variant):
     assert tot == oracle.sharded_reference(R, S, G)
 
 
+@pytest.mark.parametrize("G,log2n,dist", [(4, 26, "uniform"), (2, 25, "shuffle"), (8, 25, "random")])
+def test_shard_split_is_stable_at_size(G, log2n, dist):
+    """The stable split at sizes with thousands of chunks and several tiles per chunk: every destination's keys must be
+    exactly the input's keys of that destination in input order (a mask select on the host, no sort involved)."""
+    n = (1 << log2n) - 5                                   # ragged: the last tile and the last chunk are partial
+    R = hj.generate_data(dist, 1 << log2n, 1 << log2n, 16)[:n]
+    with hj.HashJoinContext(0) as c:
+        d_in = c.dev_alloc(n * 8); d_out = c.dev_alloc(n * 4 + 16); d_cnt = c.dev_alloc(G * 8)
+        c.copy_h2d(d_in, R)
+        c.shard_histogram(d_in, n, G, d_cnt)
+        c.shard_scatter(d_in, n, G, d_cnt, d_out)
+        cnt = np.empty(G, dtype=np.uint64); c.copy_d2h(cnt, d_cnt)
+        out = np.empty(n, dtype=np.uint32); c.copy_d2h(out, d_out)
+        for p in (d_in, d_out, d_cnt):
+            c.dev_free(p)
+    keys = R.astype(np.uint32)
+    dest = keys & np.uint32(G - 1)
+    off = 0
+    for g in range(G):
+        want = keys[dest == g]
+        assert int(cnt[g]) == want.size
+        assert np.array_equal(out[off:off + want.size], want), g
+        off += want.size
+
+
 def test_shard_split_flags_payload_bits(ctx):
     """A tuple with payload bits set cannot be told from a valid one once only keys travel: the split sends it as
     key 0 (to shard 0), where the build reports it like hj_build_dev does (HJ_ERR_KEY_RANGE)."""
