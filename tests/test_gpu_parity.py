@@ -263,6 +263,19 @@ def test_config2_size_properties(ctx):
     assert got["tableSumFull"] + got["conflictSum"] == got["inputSum"]
     want = oracle.build_probe_seq(R, S, 4)
     assert (got["conflicts"], got["totalMatches"]) == (want["conflicts"], want["totalMatches"])
+    # the bare-key entry points (what a radix shard runs after the exchange) on the same input: same table, same counts
+    with hj.HashJoinContext(0) as c:
+        dR = c.dev_alloc(n * 4 + 16); dS = c.dev_alloc(n * 4 + 16)
+        c.copy_h2d(dR + 4, R.astype(np.uint32)); c.copy_h2d(dS + 8, S.astype(np.uint32))
+        c.reserve("atomic", n, n)
+        c.build_keys(dR + 4, n, 0, 2 * n)
+        c.probe_keys(dS + 8, n)
+        c.checksums()
+        k = c.fetch()
+        assert k["buildVariant"] == 2
+        for f in ("conflicts", "totalMatches", "inputSum", "tableSumFull", "conflictSum"):
+            assert k[f] == got[f], f
+        c.dev_free(dR); c.dev_free(dS)
     del R
     R = hj.generate_data("local_shuffle", n, n, 1024)
     for algo, outsum in (("nocc", 9007199187632128), ("atomic", 9007199321849856)):   # probe_log1
