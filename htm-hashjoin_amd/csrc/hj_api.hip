@@ -53,7 +53,7 @@ struct hj_ctx {
     uint64_t *stageR = nullptr, *stageS = nullptr;
     uint64_t capStageR = 0, capStageS = 0;
     // shard helper: up to 4 inputs may sit between their histogram and their scatter
-    struct ShardPlan { const uint64_t* in = nullptr; uint64_t n = 0; uint32_t nShards = 0; void* work = nullptr; size_t cap = 0; uint64_t stamp = 0; };
+    struct ShardPlan { const uint64_t* in = nullptr; uint64_t n = 0; uint32_t nShards = 0, mode = 0; void* work = nullptr; size_t cap = 0; uint64_t stamp = 0; };
     ShardPlan shard[4];
     uint64_t shardStamp = 0;
     // timing
@@ -516,7 +516,8 @@ int hj_run(hj_ctx* c, const hj_params* params, const uint64_t* relR, uint64_t rS
 static int shard_check(hj_ctx* c, const char* who, uint64_t n, uint32_t nShards, uint32_t mode)
 {
     if (!is_pow2(nShards) || nShards > 64) return fail(c, HJ_ERR_INVALID, who);
-    if (mode != 0) return fail(c, HJ_ERR_INVALID, "shard helpers: only mode 0 (low key bits) is implemented");
+    if ((mode & 0xFFu) > 31 || (mode >> 9) != 0)
+        return fail(c, HJ_ERR_INVALID, "shard helpers: mode = digit position (0..31), optionally | HJ_SHARD_ONE_BASED");
     if (n >= 0xFFFFFFFFull) return fail(c, HJ_ERR_INVALID, "shard helpers: n must be < 2^32");
     return HJ_OK;
 }
@@ -538,8 +539,8 @@ int hj_shard_histogram_dev(hj_ctx* c, const uint64_t* dIn, uint64_t n, uint32_t 
         HJ_HIP(c, hipMalloc(&slot->work, need));
         slot->cap = need;
     }
-    slot->in = dIn; slot->n = n; slot->nShards = nShards; slot->stamp = ++c->shardStamp;
-    launch_shard_hist(dIn, n, nShards, slot->work, reinterpret_cast<unsigned long long*>(dCounts), c->stream);
+    slot->in = dIn; slot->n = n; slot->nShards = nShards; slot->mode = mode; slot->stamp = ++c->shardStamp;
+    launch_shard_hist(dIn, n, nShards, mode, slot->work, reinterpret_cast<unsigned long long*>(dCounts), c->stream);
     HJ_HIP(c, hipGetLastError());
     return HJ_OK;
 }
@@ -551,10 +552,10 @@ int hj_shard_scatter_dev(hj_ctx* c, const uint64_t* dIn, uint64_t n, uint32_t nS
     int rc = shard_check(c, "hj_shard_scatter_dev: nShards must be a power of two <= 64", n, nShards, mode);
     if (rc) return rc;
     hj_ctx::ShardPlan* slot = nullptr;
-    for (auto& sp : c->shard) if (sp.in == dIn && sp.n == n && sp.nShards == nShards && sp.work) slot = &sp;
-    if (!slot) return fail(c, HJ_ERR_STATE, "hj_shard_scatter_dev: call hj_shard_histogram_dev on this input first");
+    for (auto& sp : c->shard) if (sp.in == dIn && sp.n == n && sp.nShards == nShards && sp.mode == mode && sp.work) slot = &sp;
+    if (!slot) return fail(c, HJ_ERR_STATE, "hj_shard_scatter_dev: call hj_shard_histogram_dev on this input (same nShards and mode) first");
     HJ_HIP(c, hipSetDevice(c->device));
-    launch_shard_scatter_ordered(dIn, n, nShards, slot->work, dOutKeys, c->stream);
+    launch_shard_scatter_ordered(dIn, n, nShards, mode, slot->work, dOutKeys, c->stream);
     HJ_HIP(c, hipGetLastError());
     slot->in = nullptr;   // consumed
     return HJ_OK;

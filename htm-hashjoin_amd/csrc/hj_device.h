@@ -58,12 +58,13 @@ void launch_probe(const void* S, bool key32, uint64_t n, const uint64_t* table, 
 void launch_table_sums(const uint64_t* table, uint64_t tableSize, uint64_t halfSlots, Counters* ctr, hipStream_t s);
 // Marks the whole table valid (variant 1 clears and may touch all of it).
 void launch_set_full_range(uint64_t tableSize, Counters* ctr, hipStream_t s);
-// multi-GPU destination split (defined in hj_prj.hip: one order-preserving radix pass, tuples in, keys out)
+// multi-GPU destination split (defined in hj_prj.hip: one order-preserving radix pass, tuples in, keys out);
+// destination = (key >> digitShift) & (nShards - 1)
 size_t shard_work_bytes(uint64_t n, uint32_t nShards);
-void launch_shard_hist(const uint64_t* in, uint64_t n, uint32_t nShards, void* work, unsigned long long* counts,
-                       hipStream_t s);
-void launch_shard_scatter_ordered(const uint64_t* in, uint64_t n, uint32_t nShards, void* work, uint32_t* outKeys,
-                                  hipStream_t s);
+void launch_shard_hist(const uint64_t* in, uint64_t n, uint32_t nShards, uint32_t digitShift, void* work,
+                       unsigned long long* counts, hipStream_t s);
+void launch_shard_scatter_ordered(const uint64_t* in, uint64_t n, uint32_t nShards, uint32_t digitShift, void* work,
+                                  uint32_t* outKeys, hipStream_t s);
 
 // ---- ownership build (defined in hj_build_own.hip) ---------------------------
 size_t own_queue_bytes(uint64_t rSize);

@@ -41,7 +41,8 @@ struct PassParams {
     uint32_t nSeg;
     uint32_t chunkLen;          // multiple of kTile
     const uint32_t* chunkBase;  // [nSeg + 1] exclusive prefix of chunks per segment
-    uint32_t shift, fan;        // bin = (key >> shift) & (fan - 1)
+    uint32_t shift, fan;        // bin = ((key - bias) >> shift) & (fan - 1)
+    uint32_t bias;              // 0, or 1 for the range split of 1-based DataGen keys (shard split only)
     uint32_t zeroBad;           // shard split only: a tuple with payload bits set counts and travels as key 0, which the
                                 // receiving build reports (HJ_ERR_KEY_RANGE); PRJ reads the key word alone, as mc does
 };
@@ -147,7 +148,7 @@ k_radix_hist(const void* __restrict__ in, PassParams p, uint32_t* __restrict__ h
         bool live = false;
         auto tally = [&](uint32_t key, uint32_t at) {
             const bool ok = live && at >= r.begin && at < r.end;
-            const uint32_t bin = (key >> p.shift) & fmask;
+            const uint32_t bin = ((key - p.bias) >> p.shift) & fmask;
 #pragma unroll
             for (int b = 0; b < 16; ++b)
                 if (b < (int)p.fan) wc[b] += (uint32_t)__popcll(__ballot(ok && bin == (uint32_t)b));
@@ -179,7 +180,7 @@ k_radix_hist(const void* __restrict__ in, PassParams p, uint32_t* __restrict__ h
         const uint4 t = in4[v];
         const uint32_t i = v * EPV;
         auto one = [&](uint32_t key, uint32_t at) {
-            if (at >= r.begin && at < r.end) atomicAdd(&h[(key >> p.shift) & fmask], 1u);
+            if (at >= r.begin && at < r.end) atomicAdd(&h[((key - p.bias) >> p.shift) & fmask], 1u);
         };
         if constexpr (IN32) {
             one(t.x, i); one(t.y, i + 1); one(t.z, i + 2); one(t.w, i + 3);
@@ -694,7 +695,7 @@ void run_pass(const void* in, bool in32, uint32_t* out, uint64_t n, const uint32
     const uint32_t fan = 1u << bits;
     const PassLayout l = pass_layout(n, nSeg, fan);
     hipLaunchKernelGGL(k_chunk_base, dim3(1), dim3(64), 0, s, segIn, nSeg, l.chunkLen, w.chunkBase);
-    PassParams p{segIn, nSeg, l.chunkLen, w.chunkBase, shift, fan, 0u};
+    PassParams p{segIn, nSeg, l.chunkLen, w.chunkBase, shift, fan, 0u, 0u};
     // entries past the live chunks must be zero for the scan to be a prefix of live data only
     hipMemsetAsync(w.hist, 0, sizeof(uint32_t) * l.histEntries, s);
     if (in32) hipLaunchKernelGGL(k_radix_hist<true>, dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s, in, p, w.hist);
@@ -821,7 +822,7 @@ k_shard_scatter_stable(const uint64_t* __restrict__ in, uint32_t* __restrict__ o
 #pragma unroll
         for (int k = 0; k < kStabPer; ++k) {
             const bool ok = (okMask >> k) & 1u;
-            const uint32_t bin = key[k] & fmask;
+            const uint32_t bin = ((key[k] - p.bias) >> p.shift) & fmask;
             unsigned long long peers = __ballot(ok);
             for (int b = 0; b < bits; ++b) {
                 const bool bit = (bin >> b) & 1u;
@@ -854,7 +855,7 @@ k_shard_scatter_stable(const uint64_t* __restrict__ in, uint32_t* __restrict__ o
         }
 #pragma unroll
         for (int k = 0; k < kStabPer; ++k) {
-            const uint32_t bin = key[k] & fmask;
+            const uint32_t bin = ((key[k] - p.bias) >> p.shift) & fmask;
             const uint32_t at = cnt[(bin * kStabPer + k) * (kStabThreads / 64) + wave] + ((rk4[k / 4] >> (8 * (k % 4))) & 0xFFu);
             stage[((okMask >> k) & 1u) ? at + (at >> 5) : kDump] = key[k];
         }
@@ -865,7 +866,7 @@ k_shard_scatter_stable(const uint64_t* __restrict__ in, uint32_t* __restrict__ o
             const uint32_t q = (uint32_t)k * kStabThreads + threadIdx.x;
             if (q < valid) {
                 const uint32_t t = stage[q + (q >> 5)];
-                out[delta[t & fmask] + q] = t;
+                out[delta[((t - p.bias) >> p.shift) & fmask] + q] = t;
             }
         }
         __syncthreads();                                          // stage, cnt and delta are reused by the next tile
@@ -899,14 +900,14 @@ size_t shard_work_bytes(uint64_t n, uint32_t nShards)
            align_up(sizeof(uint32_t) * l.histEntries, 256) + align_up(sizeof(uint32_t) * (l.scanBlocks + 1), 256);
 }
 
-void launch_shard_hist(const uint64_t* in, uint64_t n, uint32_t nShards, void* work, unsigned long long* counts,
-                       hipStream_t s)
+void launch_shard_hist(const uint64_t* in, uint64_t n, uint32_t nShards, uint32_t digitShift, void* work,
+                       unsigned long long* counts, hipStream_t s)
 {
     const ShardWork w = shard_carve(work, n, nShards);
     const PassLayout l = pass_layout(n, 1, nShards);
     hipLaunchKernelGGL(k_init_seg, dim3(1), dim3(64), 0, s, w.seg0, (uint32_t)n);
     hipLaunchKernelGGL(k_chunk_base, dim3(1), dim3(64), 0, s, w.seg0, 1u, l.chunkLen, w.chunkBase);
-    PassParams p{w.seg0, 1u, l.chunkLen, w.chunkBase, 0u, nShards, 1u};
+    PassParams p{w.seg0, 1u, l.chunkLen, w.chunkBase, digitShift & 0xFFu, nShards, (digitShift >> 8) & 1u, 1u};
     (void)hipMemsetAsync(w.hist, 0, sizeof(uint32_t) * l.histEntries, s);
     hipLaunchKernelGGL(k_radix_hist<false>, dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s, static_cast<const void*>(in), p, w.hist);
     hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)l.scanBlocks), dim3(kBlock), 0, s, w.hist, l.histEntries, w.sums);
@@ -917,12 +918,12 @@ void launch_shard_hist(const uint64_t* in, uint64_t n, uint32_t nShards, void* w
 }
 
 // tuples in, bare keys out, stable: the exchange moves 4 bytes per tuple and no index
-void launch_shard_scatter_ordered(const uint64_t* in, uint64_t n, uint32_t nShards, void* work, uint32_t* outKeys,
-                                  hipStream_t s)
+void launch_shard_scatter_ordered(const uint64_t* in, uint64_t n, uint32_t nShards, uint32_t digitShift, void* work,
+                                  uint32_t* outKeys, hipStream_t s)
 {
     const ShardWork w = shard_carve(work, n, nShards);
     const PassLayout l = pass_layout(n, 1, nShards);
-    PassParams p{w.seg0, 1u, l.chunkLen, w.chunkBase, 0u, nShards, 1u};
+    PassParams p{w.seg0, 1u, l.chunkLen, w.chunkBase, digitShift & 0xFFu, nShards, (digitShift >> 8) & 1u, 1u};
     const size_t lds = sizeof(uint32_t) * ((size_t)nShards * kStabGroups + kStabTile + (kStabTile >> 5) + 1);   // <= 65.1 KiB
     static bool attrSet = false;
     if (!attrSet) {

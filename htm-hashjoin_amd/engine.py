@@ -54,6 +54,9 @@ def _params(algo, scaleOutput=2, numPartitions=64, probeLength=4, transactionSiz
     return p
 
 
+SHARD_ONE_BASED = 0x100
+
+
 class HashJoinContext:
     """One engine context bound to one GPU (hj_ctx). ``stream`` is a raw hipStream_t
     handle (e.g. torch.cuda.current_stream().cuda_stream); None = private stream."""
@@ -151,6 +154,7 @@ class HashJoinContext:
         self._check(lib.hj_copy_d2h(self._h, dst_np.ctypes.data, C.c_void_p(src_ptr), dst_np.nbytes))
 
     def shard_histogram(self, d_in, n, n_shards, d_counts, mode=0):
+        """mode = bit position of the radix digit (0 = low key bits), | SHARD_ONE_BASED for (key - 1)"""
         self._check(lib.hj_shard_histogram_dev(self._h, C.c_void_p(d_in), n, n_shards, mode, C.c_void_p(d_counts)))
 
     def shard_scatter(self, d_in, n, n_shards, d_counts, d_out_keys, mode=0):

@@ -64,15 +64,18 @@ class HipShardEngine:
         """buffer of n 32-bit keys (int32 holds the bit pattern; +4 elements so 16-byte sweeps stay inside)"""
         return self.torch.empty(int(n) + 4, dtype=self.torch.int32, device=self.dev)[: int(n)]
 
-    def histogram(self, t, n_shards):
+    def histogram(self, t, n_shards, mode=0):
         counts = self.torch.zeros(n_shards, dtype=self.torch.int64, device=self.dev)
-        self.ctx.shard_histogram(t.data_ptr(), t.numel(), n_shards, counts.data_ptr())
+        self.ctx.shard_histogram(t.data_ptr(), t.numel(), n_shards, counts.data_ptr(), mode)
         return counts
 
-    def scatter(self, t, n_shards, counts):
+    def scatter(self, t, n_shards, counts, mode=0):
         out = self.empty_keys(t.numel())
-        self.ctx.shard_scatter(t.data_ptr(), t.numel(), n_shards, counts.data_ptr(), out.data_ptr())
+        self.ctx.shard_scatter(t.data_ptr(), t.numel(), n_shards, counts.data_ptr(), out.data_ptr(), mode)
         return out
+
+    def max_key(self, t):
+        return int(t.max().item()) if t.numel() else 0
 
     def reserve(self, table_size, max_r, max_s):
         key = (table_size, max_r, max_s)
@@ -104,11 +107,55 @@ class HipShardEngine:
 class ShardedJoin:
     """Runs the sharded join for one rank. `dist` is torch.distributed (or None when world == 1)."""
 
-    def __init__(self, engine, torch, dist, rank, world):
+    ONE_BASED = 0x100                   # HJ_SHARD_ONE_BASED: split on (key - 1)
+
+    def __init__(self, engine, torch, dist, rank, world, split="low", max_key=None):
+        """split: which key bits pick the destination (both relations use the same).
+             "low"   key & (G-1): balanced whatever the keys are, but moves (G-1)/G of a relation that is held as
+                     contiguous key ranges
+             "high"  the top log2 G bits of the key domain [1, max_key] = a range split: such a relation mostly
+                     stays where it is
+             "auto"  "high" if at least 3/4 of the tuples of every rank would stay under it, else "low" -- the
+                     reference's idea of exploiting locality where the data has it, applied to the exchange
+           max_key: upper bound of the keys (DataGen: the relation size); found by one all-reduce if not given."""
         self.e, self.torch, self.dist, self.rank, self.world = engine, torch, dist, rank, world
-        self.shift = _log2(world)       # shard bits, shifted out of the home slot in the local tables
+        if split not in ("low", "high", "auto"):
+            raise ValueError(f"split must be low, high or auto, got {split!r}")
+        self.split, self.max_key = split, max_key
+        self.mode = None                # decided on the first step: digit position (| ONE_BASED)
+        self.shift = 0                  # home-slot shift of the local tables: log2 G for the low-bit split
         self.last = {}
         self._keep = None
+
+    def _all_reduce_scalar(self, v, op):
+        if self.dist is None or self.world == 1:
+            return v
+        t = self.torch.tensor([v], dtype=self.torch.int64)
+        t = t.to(self.e.dev) if hasattr(self.e, "dev") else t
+        self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op))
+        return int(t.item())
+
+    def _decide_split(self, r_local, s_local):
+        gbits = _log2(self.world)
+        low = (0, gbits)
+        if self.world == 1 or self.split == "low":
+            self.mode, self.shift = low
+            return
+        mk = self.max_key
+        if mk is None:
+            mk = self._all_reduce_scalar(max(self.e.max_key(r_local), self.e.max_key(s_local)), "MAX")
+        digit = max((max(mk, 1) - 1).bit_length() - gbits, 0)          # top log2 G bits of (key - 1)
+        high = (digit | self.ONE_BASED, 0)
+        if digit == 0:
+            self.mode, self.shift = low
+        elif self.split == "high":
+            self.mode, self.shift = high
+        else:
+            stay = int(self.e.histogram(r_local, self.world, high[0])[self.rank].item()) + \
+                   int(self.e.histogram(s_local, self.world, high[0])[self.rank].item())
+            total = r_local.numel() + s_local.numel()
+            ok = 1 if 4 * stay >= 3 * total else 0
+            self.mode, self.shift = high if self._all_reduce_scalar(ok, "MIN") else low
 
     def _exchange_counts(self, cnt_r, cnt_s):
         both = self.torch.cat([cnt_r, cnt_s]).reshape(2, self.world).t().contiguous()   # [dest][R,S]
@@ -164,12 +211,14 @@ class ShardedJoin:
         # the previous step's buffers go back to the allocator first (its kernels precede ours in stream order, its
         # transfers are done -- we waited on them): every step after the first reuses the same blocks, no hipMalloc
         self._keep = None
-        cnt_r = e.histogram(r_local, self.world)
-        cnt_s = e.histogram(s_local, self.world)
+        if self.mode is None:
+            self._decide_split(r_local, s_local)
+        cnt_r = e.histogram(r_local, self.world, self.mode)
+        cnt_s = e.histogram(s_local, self.world, self.mode)
         send_r, send_s, recv_r, recv_s = self._exchange_counts(cnt_r, cnt_s)
-        out_r = e.scatter(r_local, self.world, cnt_r)                           # keys, grouped by destination
+        out_r = e.scatter(r_local, self.world, cnt_r, self.mode)                # keys, grouped by destination
         got_r, work_r = self._exchange_async(out_r, send_r, recv_r)
-        out_s = e.scatter(s_local, self.world, cnt_s)
+        out_s = e.scatter(s_local, self.world, cnt_s, self.mode)
         got_s, work_s = self._exchange_async(out_s, send_s, recv_s)
         e.reserve(table_size, got_r.numel(), got_s.numel())
         for w in work_r:
@@ -179,7 +228,8 @@ class ShardedJoin:
             w.wait()
         e.probe(got_s)
         self.last = {"sent_r": sum(send_r) - send_r[self.rank], "sent_s": sum(send_s) - send_s[self.rank],
-                     "recv_r": got_r.numel(), "recv_s": got_s.numel()}
+                     "recv_r": got_r.numel(), "recv_s": got_s.numel(),
+                     "split": "low key bits" if self.mode == 0 else f"high key bits (range split, digit at bit {self.mode & 0xFF})"}
         self._keep = (out_r, out_s, got_r, got_s)   # alive until the stream has consumed them
 
     def result(self):
@@ -239,25 +289,37 @@ def bench_sharded(args, torch, dist, hj, rank, world, local_rank):
     s_local = torch.from_numpy(S.view("int64")).to(f"cuda:{local_rank}")
     del R, S
     eng = HipShardEngine(hj, torch, local_rank, build_variant=args.build_variant)
-    job = ShardedJoin(eng, torch, dist, rank, world)
     table_size = 2 * n
+    total_keys = min(world * n, wrap)                                # DataGen: keys lie in [1, relation size]
 
-    def step():
-        job.step(r_local, s_local, table_size)
+    def timed(split, steps, warmup):
+        job = ShardedJoin(eng, torch, dist, rank, world, split=split,
+                          max_key=None if args.dist == "random" else total_keys)
+        for _ in range(warmup):
+            job.step(r_local, s_local, table_size)
+        eng.sync(); dist.barrier(); eng.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            job.step(r_local, s_local, table_size)
+        eng.sync(); dist.barrier(); eng.sync()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return job, float(t.item())
 
-    for _ in range(args.warmup):
-        step()
-    eng.sync(); dist.barrier(); eng.sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    eng.sync(); dist.barrier(); eng.sync()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    job, dt = timed(args.split, args.steps, args.warmup)
     res = job.result()
     total = 2 * n * world
+    # the same join with the other split, a few steps, for the record (not part of `value`)
+    alt = None
+    if world > 1:
+        other = "high" if job.mode == 0 else "low"
+        k = max(1, min(3, args.steps))
+        ajob, adt = timed(other, k, 1)
+        ares = ajob.result()
+        alt = {"split": ares["exchange"]["split"], "steps": k, "ms_per_step": adt / k * 1e3,
+               "mtuples_per_s": total * k / adt / 1e6, "sent_r": ares["exchange"]["sent_r"], "sent_s": ares["exchange"]["sent_s"],
+               "conflicts": ares["conflicts"], "totalMatches": ares["totalMatches"]}
     unique_domain = width == n
     unique = unique_domain and args.dist in ("sorted", "shuffle", "local_shuffle")
     line = {
@@ -268,8 +330,10 @@ def bench_sharded(args, torch, dist, hj, rank, world, local_rank):
         "vs_baseline": None, "dtype": "u64 tuples (u32 key), integer",
         "data": "synthetic (DataGen restatement per rank on its own key range)",
         "config": {"workload": f"radix-sharded open-addressing build+probe over {world} GPUs, |R|=|S|={n} per GPU "
-                               f"({n * world} in total), dataDistr={args.dist} W={window}; step = destination histogram + "
-                               "order-preserving scatter to 32-bit keys + all-to-all (R and S, overlapped) + local table build/probe",
+                               f"({n * world} in total), dataDistr={args.dist} W={window}, every rank holding one contiguous "
+                               f"piece of the near-sorted relations; destination = {res['exchange']['split']} (--split "
+                               f"{args.split}); step = destination histogram + stable split to 32-bit keys + all-to-all "
+                               "(R and S, overlapped) + local table build/probe",
                    "algo": "atomic", "rSize": n * world,
                    "sSize": n * world, "per_gpu_rSize": n, "dataDistr": args.dist, "shuffleRange": window,
                    "parallelism": f"radix{world}"},
@@ -279,6 +343,7 @@ def bench_sharded(args, torch, dist, hj, rank, world, local_rank):
                    "tableSum_plus_conflictSum_eq_inputSum": res["tableSumFull"] + res["conflictSum"] == res["inputSum"]},
         "exchange": res["exchange"], "local_kernel_us": {k: res["local"][k] for k in ("clear_us", "build_us", "probe_us")},
         "local_build_variant": res["local"]["buildVariant"],
+        "other_split": alt,
         "roofline": _local_roofline(res), "cpu_baseline": None,
     }
     eng.close()

@@ -169,9 +169,15 @@ int hj_fetch_result(hj_ctx *ctx, hj_result *out);
 int hj_export_table(hj_ctx *ctx, uint64_t *host_table, uint64_t tableSize);
 
 /* ---- multi-GPU sharding helpers (new design) ---------------- */
-/* dest(key) = key & (nShards-1): the low key bits (HASH_BIT_MODULO,
- * parallel_radix_join.c:59); nShards a power of two <= 64. `mode` must be 0
- * (reserved for a range split). */
+/* dest(key) = ((key - b) >> d) & (nShards-1), nShards a power of two <= 64, with d = mode & 0xFF the bit position
+ * of the radix digit and b = 1 if mode has HJ_SHARD_ONE_BASED set, else 0: HASH_BIT_MODULO(key, MASK, R) of
+ * parallel_radix_join.c:59 with R = d. d = 0 takes the low key bits: balanced for any key distribution, but on a
+ * relation whose pieces are contiguous key ranges (the reference's near-sorted inputs, held piecewise) all but
+ * 1/nShards of the tuples change GPU. d = (bits of the key domain) - log2(nShards) takes the HIGH bits, i.e. a
+ * range split: such pieces mostly stay where they are and only what does not fit a rank's range moves
+ * (HJ_SHARD_ONE_BASED makes the ranges of DataGen's keys 1..N come out even). Both relations of a join must use
+ * the same mode. */
+#define HJ_SHARD_ONE_BASED 0x100u
 /* Counts tuples per destination into dCounts[nShards] (device, uint64) and keeps
  * the per-chunk write cursors for the scatter of the same input. Async. */
 int hj_shard_histogram_dev(hj_ctx *ctx, const uint64_t *dIn, uint64_t n,

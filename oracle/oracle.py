@@ -112,16 +112,19 @@ def build_probe_seq_ts(relR, relS, table_size, home_shift=0, probe_length=4, wan
     return d
 
 
-def sharded_reference(relR, relS, n_shards, probe_length=4):
-    """What the radix-sharded join computes: shard g takes the tuples with key & (G-1) == g in global
-    input order and runs the sequential build+probe into a table of 2*|R|/G slots with home slot
-    (key >> log2 G) & mask; counters are summed over shards."""
-    strip = (n_shards - 1).bit_length()
+def sharded_reference(relR, relS, n_shards, probe_length=4, digit_shift=0, one_based=False):
+    """What the radix-sharded join computes: shard g takes the tuples with ((key - b) >> digit_shift) & (G-1) == g
+    (b = 1 if one_based) in global input order and runs the sequential build+probe into a table of 2*|R|/G slots;
+    counters are summed over shards. digit_shift = 0 (low key bits): home slot (key >> log2 G) & mask, the shard bits
+    carry no information inside a shard. digit_shift > 0 (high bits, a range split): home slot key & mask, as in the
+    single table."""
+    strip = (n_shards - 1).bit_length() if digit_shift == 0 else 0
+    b = np.uint64(1 if one_based else 0)
     table_size = 2 * relR.size // n_shards
     tot = {"conflicts": 0, "totalMatches": 0, "inputSum": 0, "tableSumFull": 0, "conflictSum": 0}
     for g in range(n_shards):
-        Rg = relR[(relR & np.uint64(n_shards - 1)) == g]
-        Sg = relS[(relS & np.uint64(n_shards - 1)) == g]
+        Rg = relR[(((relR - b) >> np.uint64(digit_shift)) & np.uint64(n_shards - 1)) == g]
+        Sg = relS[(((relS - b) >> np.uint64(digit_shift)) & np.uint64(n_shards - 1)) == g]
         r = build_probe_seq_ts(Rg, Sg, table_size, strip, probe_length)
         for k in tot:
             tot[k] += r[k]

@@ -378,6 +378,59 @@ def test_shard_split_is_stable_at_size(G, log2n, dist):
         off += want.size
 
 
+@pytest.mark.parametrize("dist,window", [("uniform", 16), ("shuffle", 16)])
+def test_range_split_on_one_gpu(dist, window):
+    """The HIGH-bit (range) split, G = 4 ranks emulated on one GPU: dest = ((key - 1) >> 14) & 3 for keys 1..2^16,
+    stable, and the shards (home slot = key & mask, no shift) equal the sharded reference."""
+    G, n = 4, 1 << 16
+    n_local = n // G
+    mode = 14 | hj.SHARD_ONE_BASED
+    R = oracle.generate_data(dist, n, n, window)
+    S = oracle.generate_data("sorted", n)
+    inbox_r = [[] for _ in range(G)]; inbox_s = [[] for _ in range(G)]
+    moved = 0
+    with hj.HashJoinContext(0) as c:
+        d_in = c.dev_alloc(n_local * 8); d_out = c.dev_alloc(n_local * 4 + 16); d_cnt = c.dev_alloc(G * 8)
+        for src in range(G):
+            for rel, inbox in ((R, inbox_r), (S, inbox_s)):
+                piece = rel[src * n_local:(src + 1) * n_local]
+                c.copy_h2d(d_in, piece)
+                c.shard_histogram(d_in, n_local, G, d_cnt, mode)
+                with pytest.raises(hj.HashJoinError):                     # the scatter must name the histogram's mode
+                    c.shard_scatter(d_in, n_local, G, d_cnt, d_out, 0)
+                c.shard_scatter(d_in, n_local, G, d_cnt, d_out, mode)
+                cnt = np.empty(G, dtype=np.uint64); c.copy_d2h(cnt, d_cnt)
+                out = np.empty(n_local, dtype=np.uint32); c.copy_d2h(out, d_out)
+                dest = (((piece - np.uint64(1)) >> np.uint64(14)) & np.uint64(G - 1)).astype(np.int64)
+                assert np.array_equal(out, piece[np.argsort(dest, kind="stable")].astype(np.uint32))
+                moved += int((dest != src).sum())
+                off = 0
+                for g in range(G):
+                    inbox[g].append(out[off:off + int(cnt[g])]); off += int(cnt[g])
+        for p in (d_in, d_out, d_cnt):
+            c.dev_free(p)
+    if dist == "uniform":
+        assert moved < n // 100                                           # contiguous pieces of a near-sorted relation stay put
+    tot = {k: 0 for k in ("conflicts", "totalMatches", "inputSum", "tableSumFull", "conflictSum")}
+    for g in range(G):
+        got_r = np.concatenate(inbox_r[g]); got_s = np.concatenate(inbox_s[g])
+        with hj.HashJoinContext(0) as c:
+            r = n_local
+            while r < got_r.size:
+                r *= 2
+            c.reserve("atomic", r, got_s.size)
+            d_r = c.dev_alloc(got_r.size * 4 + 16); d_s = c.dev_alloc(got_s.size * 4 + 16)
+            c.copy_h2d(d_r, got_r); c.copy_h2d(d_s, got_s)
+            c.build_keys(d_r, got_r.size, 0, 2 * n_local)
+            c.probe_keys(d_s, got_s.size)
+            c.checksums()
+            res = c.fetch()
+            for k in tot:
+                tot[k] += res[k]
+            c.dev_free(d_r); c.dev_free(d_s)
+    assert tot == oracle.sharded_reference(R, S, G, digit_shift=14, one_based=True)
+
+
 def test_shard_split_flags_payload_bits(ctx):
     """A tuple with payload bits set cannot be told from a valid one once only keys travel: the split sends it as
     key 0 (to shard 0), where the build reports it like hj_build_dev does (HJ_ERR_KEY_RANGE)."""

@@ -23,16 +23,24 @@ class OracleShardEngine:
     def empty_keys(self, n):
         return torch.empty(int(n), dtype=torch.int32)
 
-    def histogram(self, t, n_shards):
-        k = t.numpy().view(np.uint64)
-        return torch.from_numpy(np.bincount((k & np.uint64(n_shards - 1)).astype(np.int64), minlength=n_shards)).to(torch.int64)
+    @staticmethod
+    def _dest(k, n_shards, mode):
+        """hj_shard_histogram_dev: ((key - b) >> d) & (nShards - 1), d = mode & 0xFF, b = 1 if HJ_SHARD_ONE_BASED"""
+        k32 = k.astype(np.uint32) - np.uint32(1 if mode & 0x100 else 0)
+        return ((k32 >> np.uint32(mode & 0xFF)) & np.uint32(n_shards - 1)).astype(np.int64)
 
-    def scatter(self, t, n_shards, counts):
+    def histogram(self, t, n_shards, mode=0):
+        k = t.numpy().view(np.uint64)
+        return torch.from_numpy(np.bincount(self._dest(k, n_shards, mode), minlength=n_shards)).to(torch.int64)
+
+    def scatter(self, t, n_shards, counts, mode=0):
         """grouped by destination, input order kept inside each (what hj_shard_scatter_dev guarantees), keys only"""
         k = t.numpy().view(np.uint64)
-        dest = (k & np.uint64(n_shards - 1)).astype(np.int64)
-        order = np.argsort(dest, kind="stable")
+        order = np.argsort(self._dest(k, n_shards, mode), kind="stable")
         return torch.from_numpy(k[order].astype(np.uint32).view(np.int32).copy())
+
+    def max_key(self, t):
+        return int(t.max().item()) if t.numel() else 0
 
     def reserve(self, table_size, max_r, max_s):
         pass
@@ -59,7 +67,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, dist_name, window, n_local, out):
+def _worker(rank, world, port, dist_name, window, n_local, out, split="low"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import htm_hashjoin_amd as hj
@@ -69,12 +77,15 @@ def _worker(rank, world, port, dist_name, window, n_local, out):
     S = hj.generate_data("sorted", n)
     r_local = torch.from_numpy(R[rank * n_local:(rank + 1) * n_local].view(np.int64).copy())
     s_local = torch.from_numpy(S[rank * n_local:(rank + 1) * n_local].view(np.int64).copy())
-    job = ShardedJoin(OracleShardEngine(), torch, dist, rank, world)
+    job = ShardedJoin(OracleShardEngine(), torch, dist, rank, world, split=split)
     job.max_msg_tuples = 700            # force the exchange into several messages per peer
     job.step(r_local, s_local, 2 * n_local)
     res = job.result()
     if rank == 0:
-        out.put({k: res[k] for k in ("conflicts", "totalMatches", "inputSum", "tableSumFull", "conflictSum")})
+        d = {k: res[k] for k in ("conflicts", "totalMatches", "inputSum", "tableSumFull", "conflictSum")}
+        d["mode"] = job.mode
+        d["sent"] = res["exchange"]["sent_r"] + res["exchange"]["sent_s"]
+        out.put(d)
     dist.destroy_process_group()
 
 
@@ -96,9 +107,42 @@ def test_sharded_join_matches_sharded_reference(world, dist_name, window):
     R = oracle.generate_data(dist_name, n, n, window)
     S = oracle.generate_data("sorted", n)
     want = oracle.sharded_reference(R, S, world)
+    assert got.pop("mode") == 0 and got.pop("sent") > 0
     assert got == want
     if dist_name == "local_shuffle":
         assert got["conflicts"] == 0 and got["totalMatches"] == n
+
+
+@pytest.mark.parametrize("split,dist_name,window,expect_high", [
+    ("high", "uniform", 16, True), ("auto", "uniform", 16, True), ("auto", "local_shuffle", 1024, True),
+    ("auto", "shuffle", 16, False), ("high", "shuffle", 16, True)])
+def test_range_split(split, dist_name, window, expect_high):
+    """Destination by the HIGH key bits (a range split): ranks that hold contiguous pieces of a near-sorted relation
+    keep almost everything; "auto" takes it only then (a shuffled relation falls back to the low bits). Either way the
+    totals equal the sharded reference for the digit that was used."""
+    world, n_local = 4, 1 << 12
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, PORT[0], dist_name, window, n_local, q, split)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n = n_local * world
+    R = oracle.generate_data(dist_name, n, n, window)
+    S = oracle.generate_data("sorted", n)
+    mode, sent = got.pop("mode"), got.pop("sent")
+    if expect_high:
+        assert mode == (12 | 0x100)                      # keys 1..2^14 over 4 ranks: digit of (key - 1) at bit 12
+        want = oracle.sharded_reference(R, S, world, digit_shift=12, one_based=True)
+        if dist_name != "shuffle":
+            assert sent < n // 8, sent                   # near-sorted pieces: next to nothing crosses the wire
+    else:
+        assert mode == 0
+        want = oracle.sharded_reference(R, S, world)
+    assert got == want
 
 
 PORT = [0]
