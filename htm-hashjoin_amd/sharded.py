@@ -94,6 +94,13 @@ class HipShardEngine:
     def probe(self, s_keys):
         self.ctx.probe_keys(s_keys.data_ptr(), s_keys.numel())
 
+    def build_tuples(self, r_tuples):
+        """the single-GPU operator on a rank's own 8-byte tuples (table of 2 * len slots, no home shift)"""
+        self.ctx.build(r_tuples.data_ptr(), r_tuples.numel())
+
+    def probe_tuples(self, s_tuples):
+        self.ctx.probe(s_tuples.data_ptr(), s_tuples.numel())
+
     def finish(self):
         self.ctx.checksums()
         r = self.ctx.fetch()
@@ -216,6 +223,18 @@ class ShardedJoin:
         cnt_r = e.histogram(r_local, self.world, self.mode)
         cnt_s = e.histogram(s_local, self.world, self.mode)
         send_r, send_s, recv_r, recv_s = self._exchange_counts(cnt_r, cnt_s)
+        split_name = "low key bits" if self.mode == 0 else f"high key bits (range split, digit at bit {self.mode & 0xFF})"
+        moved = sum(send_r) - send_r[self.rank] + sum(send_s) - send_s[self.rank]
+        if self.world > 1 and self.shift == 0 and table_size == 2 * r_local.numel() and \
+                self._all_reduce_scalar(moved, "SUM") == 0:
+            # a range split under which every tuple already sits on its rank: nothing to regroup, nothing to send --
+            # the rank's piece IS its shard, in input order
+            e.reserve(table_size, r_local.numel(), s_local.numel())
+            e.build_tuples(r_local)
+            e.probe_tuples(s_local)
+            self.last = {"sent_r": 0, "sent_s": 0, "recv_r": r_local.numel(), "recv_s": s_local.numel(),
+                         "split": split_name + "; no tuple had to move: pieces joined in place"}
+            return
         out_r = e.scatter(r_local, self.world, cnt_r, self.mode)                # keys, grouped by destination
         got_r, work_r = self._exchange_async(out_r, send_r, recv_r)
         out_s = e.scatter(s_local, self.world, cnt_s, self.mode)
@@ -228,8 +247,7 @@ class ShardedJoin:
             w.wait()
         e.probe(got_s)
         self.last = {"sent_r": sum(send_r) - send_r[self.rank], "sent_s": sum(send_s) - send_s[self.rank],
-                     "recv_r": got_r.numel(), "recv_s": got_s.numel(),
-                     "split": "low key bits" if self.mode == 0 else f"high key bits (range split, digit at bit {self.mode & 0xFF})"}
+                     "recv_r": got_r.numel(), "recv_s": got_s.numel(), "split": split_name}
         self._keep = (out_r, out_s, got_r, got_s)   # alive until the stream has consumed them
 
     def result(self):

@@ -49,6 +49,13 @@ class OracleShardEngine:
         # position in the receive buffer = insertion order
         self._built = (r_keys.numpy().view(np.uint32).astype(np.uint64), home_shift, table_size)
 
+    def build_tuples(self, r_tuples):
+        self._built = (r_tuples.numpy().view(np.uint64).copy(), 0, 2 * r_tuples.numel())
+
+    def probe_tuples(self, s_tuples):
+        keys, home_shift, table_size = self._built
+        self._res = oracle.build_probe_seq_ts(keys, s_tuples.numpy().view(np.uint64).copy(), table_size, home_shift)
+
     def probe(self, s_keys):
         keys, home_shift, table_size = self._built
         s = s_keys.numpy().view(np.uint32).astype(np.uint64)
@@ -143,6 +150,26 @@ def test_range_split(split, dist_name, window, expect_high):
         assert mode == 0
         want = oracle.sharded_reference(R, S, world)
     assert got == want
+
+
+def test_range_split_nothing_moves_joins_in_place():
+    """`sorted` pieces under the range split: every tuple is already home -- the ranks join their pieces in place
+    (no split, no exchange) and the totals still equal the sharded reference."""
+    world, n_local = 2, 1 << 12
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, PORT[0], "sorted", 16, n_local, q, "auto")) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n = n_local * world
+    R = oracle.generate_data("sorted", n); S = oracle.generate_data("sorted", n)
+    assert got.pop("mode") == (12 | 0x100) and got.pop("sent") == 0
+    assert got == oracle.sharded_reference(R, S, world, digit_shift=12, one_based=True)
+    assert got["totalMatches"] == n
 
 
 PORT = [0]
