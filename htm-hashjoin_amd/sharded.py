@@ -4,8 +4,8 @@ New design (the reference is single-process shared memory). One pr
 (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm). Rank g holds the g-th contiguous
 piece of R and of S. Per join:
 
-  1. histogram   destination of a tuple = key & (G-1)   (HASH_BIT_MODULO on the low bits,
-                 mc/src/parallel_radix_join.c:59)                     -> hj_shard_histogram_dev
+  1. histogram   destination of a tuple = one radix digit of its key (HASH_BIT_MODULO, mc/src/parallel_radix_join.c:59):
+                 the low log2 G bits, or the high ones = a range split (see ShardedJoin)  -> hj_shard_histogram_dev
   2. counts      one all_to_all_single of the G per-destination counts (R and S together)
   3. scatter     tuples grouped by destination IN INPUT ORDER, written as bare 32-bit keys (a DataGen
                  tuple is its key): 4 bytes per tuple cross the links            -> hj_shard_scatter_dev
@@ -17,12 +17,13 @@ piece of R and of S. Per join:
                  order, position in the received buffer is GLOBAL input order -- the reference's
                  insertion order survives the exchange without any index travelling
   5. local join  open-addressing build of the received R keys into a table of 2*|R_local| slots, priority
-                 = position in the received buffer, home slot = (key >> log2 G) & mask (the shard bits
-                 are the same for every local key), probe with the received S keys
+                 = position in the received buffer, home slot = (key >> log2 G) & mask under the low-bit split
+                 (the shard bits are the same for every local key), key & mask under the range split; probe
+                 with the received S keys
                                                                      -> hj_build_keys_dev / hj_probe_keys_dev
   6. counters    one all_reduce(sum) of {conflicts, matches, sums}
 
-Result semantics: shard g's table holds the tuples whose low key bits are g, inserted in GLOBAL
+Result semantics: shard g's table holds the tuples whose destination digit is g, inserted in GLOBAL
 input order with the reference's probe budget; the test suite restates exactly that on the CPU and
 compares bit-exactly (tests/test_sharded_gloo.py). For G = 1 this is the single-GPU operator. For unique keys
 (sorted / shuffle / local_shuffle) the totals equal the single-table result (conflicts 0,
