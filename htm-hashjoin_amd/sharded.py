@@ -285,23 +285,29 @@ def bench_sharded(args, torch, dist, hj, rank, world, local_rank):
     Globally the relation is the near-sorted one the reference generates, cut into contiguous pieces: rank g's
     piece = DataGen over its own key range, drawn piecewise (a rank cannot afford the serial rand() stream of its
     neighbours). Keys are 32 bits: while world * n <= 2^32 - 1 rank g owns the keys (g*n, (g+1)*n]; beyond that
-    (8 x 2^30 tuples, 2^32 keys) the key domain is still cut into `world` contiguous ranges and a rank's n draws
-    are squeezed into its range -- every key about world*n / 2^32 times, duplicates adjacent, as in a globally
-    sorted relation with more tuples than keys."""
+    (8 x 2^30 tuples, 2^32 keys) the key space is cut into `world` equal contiguous ranges and a rank's n draws are
+    squeezed into its range -- every key about world*n / 2^32 times, duplicates adjacent, as in a globally sorted
+    relation with more tuples than keys."""
     strip = _log2(world)
     n = (1 << args.log2n) >> (strip if args.strong else 0)          # tuples per rank and relation
     window = args.shuffle_range
     wrap = (1 << 32) - 1
-    width = min(n, wrap // world)                                    # keys in a rank's range
+    # rank g's key range: (g*n, (g+1)*n] while the whole relation fits the 32-bit key space; otherwise the g-th of
+    # `world` equal cuts of that space (the last one ends at 2^32 - 1)
+    if world * n <= wrap:
+        lo, width = rank * n, n
+    else:
+        cut = (wrap + world) // world                                 # 2^32 / world for a power-of-two world
+        lo, width = rank * cut, min(cut, wrap - rank * cut)
     R = hj.generate_data(args.dist, n, n, window)                    # values in [1, n] (uniform and the unique-key kinds)
 
-    def to_range(v):                                                 # [1, n] -> (rank*width, (rank+1)*width], order kept
+    def to_range(v):                                                 # [1, n] -> (lo, lo + width], order kept
         if args.dist == "random":                                    # 31-bit random keys: no range to speak of
             return v
         v = v - np.uint64(1)
         if width != n:
             v = (v * np.uint64(width)) // np.uint64(n)
-        return v + np.uint64(rank * width + 1)
+        return v + np.uint64(lo + 1)
     r_local = torch.from_numpy(to_range(R).view("int64")).to(f"cuda:{local_rank}")
     # S as main.cpp:91-97 builds it: sorted 1..N on the same key range (for `random`: R itself)
     S = R.copy() if args.dist == "random" else to_range(np.arange(1, n + 1, dtype=np.uint64))
@@ -309,7 +315,7 @@ def bench_sharded(args, torch, dist, hj, rank, world, local_rank):
     del R, S
     eng = HipShardEngine(hj, torch, local_rank, build_variant=args.build_variant)
     table_size = 2 * n
-    total_keys = min(world * n, wrap)                                # DataGen: keys lie in [1, relation size]
+    total_keys = min(world * n, wrap)                                # the keys lie in [1, relation size] (or the whole key space)
 
     def timed(split, steps, warmup):
         job = ShardedJoin(eng, torch, dist, rank, world, split=split,
@@ -339,7 +345,7 @@ def bench_sharded(args, torch, dist, hj, rank, world, local_rank):
         alt = {"split": ares["exchange"]["split"], "steps": k, "ms_per_step": adt / k * 1e3,
                "mtuples_per_s": total * k / adt / 1e6, "sent_r": ares["exchange"]["sent_r"], "sent_s": ares["exchange"]["sent_s"],
                "conflicts": ares["conflicts"], "totalMatches": ares["totalMatches"]}
-    unique_domain = width == n
+    unique_domain = world * n <= wrap
     unique = unique_domain and args.dist in ("sorted", "shuffle", "local_shuffle")
     line = {
         "metric": "Mtuples/sec build+probe, |R|=|S|=1B uint32, uniform vs local_shuffle",
