@@ -3,6 +3,14 @@ import sys
 
 import pytest
 
+try:
+    # torch ships its own HIP runtime; it has to be the first one loaded into the process (as in bench.py), or torch
+    # finds "no HIP GPUs" once libhtmjoin_hip.so has pulled in the system one. Only the in-process multi-rank test
+    # (test_gpu_parity.py) uses torch on the GPU; everything else goes through the C ABI alone.
+    import torch  # noqa: F401
+except Exception:  # noqa: BLE001
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -6,6 +6,12 @@ import os
 import numpy as np
 import pytest
 
+try:                                     # torch has to bring HIP up before the library does, or it finds no device later
+    import torch
+    _TORCH_GPU = bool(torch.cuda.is_available()) and torch.zeros(1, device="cuda:0").numel() == 1
+except Exception:                        # noqa: BLE001 -- no torch / no GPU: only the in-process multi-rank test needs it
+    _TORCH_GPU = False
+
 import htm_hashjoin_amd as hj
 from htm_hashjoin_amd import _lib
 from oracle import oracle
@@ -429,6 +435,61 @@ def test_range_split_on_one_gpu(dist, window):
                 tot[k] += res[k]
             c.dev_free(d_r); c.dev_free(d_s)
     assert tot == oracle.sharded_reference(R, S, G, digit_shift=14, one_based=True)
+
+
+@pytest.mark.parametrize("world,dist,window,split,expect", [
+    (2, "uniform", 16, "low", "low"), (4, "uniform", 16, "auto", "high"), (2, "uniform", 16, "high", "high"),
+    (4, "shuffle", 16, "auto", "low"), (2, "sorted", 16, "auto", "in place"), (4, "local_shuffle", 1024, "auto", "high")])
+def test_sharded_join_product_engine_in_process_ranks(world, dist, window, split, expect):
+    """htm_hashjoin_amd/sharded.py end to end with the PRODUCT engine (HipShardEngine) at world 2 and 4 on one GPU: the
+    ranks are threads of this process and exchange through tests/loopback_dist.py instead of RCCL. Low-bit split, range
+    split, auto, and the join-in-place case; totals must equal the sharded reference of the split that ran."""
+    import threading
+    assert _TORCH_GPU, "torch could not initialise the GPU"
+    from htm_hashjoin_amd.sharded import HipShardEngine, ShardedJoin
+    from loopback_dist import Hub, LoopbackDist
+    n_local = 1 << 16
+    n = n_local * world
+    R = oracle.generate_data(dist, n, n, window)
+    S = oracle.generate_data("sorted", n)
+    hub = Hub(world)
+    out, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            eng = HipShardEngine(hj, torch, 0)
+            job = ShardedJoin(eng, torch, LoopbackDist(hub, rank), rank, world, split=split, max_key=n)
+            job.max_msg_tuples = 5000                                     # several messages per peer
+            r_local = torch.from_numpy(R[rank * n_local:(rank + 1) * n_local].view(np.int64).copy()).to("cuda:0")
+            s_local = torch.from_numpy(S[rank * n_local:(rank + 1) * n_local].view(np.int64).copy()).to("cuda:0")
+            for _ in range(2):                                            # second step: buffers are reused
+                job.step(r_local, s_local, 2 * n_local)
+            res = job.result()
+            res["mode"] = job.mode
+            out[rank] = res
+            eng.close()
+        except Exception as e:                                            # noqa: BLE001 -- reported by the main thread
+            errs.append((rank, repr(e)))
+            hub.bar.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errs, errs
+    got = out[0]
+    bits = (n - 1).bit_length() - (world.bit_length() - 1)
+    if expect == "low":
+        assert got["mode"] == 0 and got["exchange"]["sent_r"] > 0
+        want = oracle.sharded_reference(R, S, world)
+    else:
+        assert got["mode"] == (bits | hj.SHARD_ONE_BASED)
+        want = oracle.sharded_reference(R, S, world, digit_shift=bits, one_based=True)
+        assert ("in place" in got["exchange"]["split"]) == (expect == "in place")
+    for k in want:
+        assert got[k] == want[k], (k, got[k], want[k])
+    assert all(o["conflicts"] == got["conflicts"] for o in out)           # the all-reduce reached every rank
 
 
 def test_shard_split_flags_payload_bits(ctx):
