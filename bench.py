@@ -239,6 +239,11 @@ def main():
         ctx2 = hj.HashJoinContext(local_rank, stream=stream)
         extra["prj_local_shuffle_1024"] = prj_leg(torch, hj, ctx2, n, "local_shuffle", 1024, k2, 1, S_dev)
         ctx2.close()
+        if a.log2n > 27:      # BASELINE configs[1] at its own size: |R| = |S| = 2^27, uniform (the reference's experiment size)
+            ctx3 = hj.HashJoinContext(local_rank, stream=stream)
+            extra["oa_uniform_2p27"], _ = oa_leg(torch, hj, ctx3, 1 << 27, a.dist, a.shuffle_range, 2 * a.steps, 2,
+                                                 variant=a.build_variant)
+            ctx3.close()
     ctx.close()
     del S_dev
     torch.cuda.empty_cache()
