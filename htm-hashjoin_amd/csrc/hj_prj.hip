@@ -472,6 +472,11 @@ constexpr int kJoinPre = 16;   // tuples per thread and relation prefetched in r
 // the next partition are already in flight into the other register set (explicit vmcnt wait at the top,
 // one unconditional clamped load path -- see hj_build_own.hip for why). Measured at 2^30: 13.4 ms -> see
 // profiles/.
+// DIRECT (radixBits >= 16): the part of a key that tells the keys of a partition apart, k = key >> radixBits, has at
+// most 16 bits, so the 128 KiB of LDS hold one 16-bit counter for EVERY possible k: build = one counter increment,
+// probe = one read, no hashing and no probe walks (the hash-table version spends 26 VALU instructions per tuple on
+// them, PMC). Counters cannot overflow while |R partition| <= 65535; larger ones take the hash-table path.
+template <bool DIRECT>
 __global__ void __launch_bounds__(kJoinThreads)
 k_prj_join(const uint32_t* __restrict__ partR, const uint32_t* __restrict__ offR,
            const uint32_t* __restrict__ partS, const uint32_t* __restrict__ offS,
@@ -520,7 +525,43 @@ k_prj_join(const uint32_t* __restrict__ partR, const uint32_t* __restrict__ offR
         const uint32_t nS = se - sb;
         const uint32_t idxMask = next_pow2_u32(nR) - 1;  // bucket idx mask, :242-245
 
-        if (nR <= kJoinBlockTuples) {
+        if (DIRECT && nR <= 65535u) {
+            // ---- direct-addressed counters: tab[k >> 1] holds the counts of k = 2i (low half) and 2i + 1 (high half) ----
+            for (uint32_t i = threadIdx.x; i < kJoinSlots; i += kJoinThreads) tab[i] = 0u;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < kJoinPre; ++j) {
+                if (j * kJoinThreads + threadIdx.x < nR) {
+                    const uint32_t k = bufR[j] >> radixBits;
+                    checksum += k & idxMask;                          // :249,256
+                    atomicAdd(&tab[k >> 1], 1u << (16u * (k & 1u)));
+                }
+            }
+            for (uint32_t i = rb + kJoinPre * kJoinThreads + threadIdx.x; i < re; i += kJoinThreads) {
+                const uint32_t k = partR[i] >> radixBits;
+                checksum += k & idxMask;
+                atomicAdd(&tab[k >> 1], 1u << (16u * (k & 1u)));
+            }
+            __syncthreads();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // S(pid) has landed; bufR is free
+            __builtin_amdgcn_sched_barrier(0);
+            load_R(pid + gridDim.x);                           // in flight while S is probed
+            __builtin_amdgcn_sched_barrier(0);
+            uint32_t m32 = 0;                                  // <= 65535 per probe, a few dozen probes per thread
+#pragma unroll
+            for (int j = 0; j < kJoinPre; ++j) {
+                if (j * kJoinThreads + threadIdx.x < nS) {
+                    const uint32_t k = bufS[j] >> radixBits;
+                    m32 += (tab[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;      // :268-271, all equal keys at once
+                }
+            }
+            matches += m32;
+            for (uint32_t i = sb + kJoinPre * kJoinThreads + threadIdx.x; i < se; i += kJoinThreads) {
+                const uint32_t k = partS[i] >> radixBits;
+                matches += (tab[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;
+            }
+            __syncthreads();
+        } else if (nR <= kJoinBlockTuples) {
             // ---- the common case: the whole R partition fits one LDS table ----
             for (uint32_t i = threadIdx.x; i < kJoinSlots; i += kJoinThreads) tab[i] = kEmpty32;
             __syncthreads();
@@ -741,7 +782,9 @@ void launch_prj(const PrjPlan& pl, const PrjBuffers& buf, const uint64_t* R, uin
     const uint32_t P = 1u << pl.radixBits;
     static bool attrSet = false;
     if (!attrSet) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_prj_join),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_prj_join<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kJoinSlots * sizeof(uint32_t));
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_prj_join<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, kJoinSlots * sizeof(uint32_t));
         attrSet = true;
     }
@@ -752,7 +795,13 @@ void launch_prj(const PrjPlan& pl, const PrjBuffers& buf, const uint64_t* R, uin
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&nCU, hipDeviceAttributeMultiprocessorCount, dev);
     }
     const unsigned grid = P < (uint32_t)nCU ? P : (unsigned)nCU;   // one persistent workgroup per CU
-    hipLaunchKernelGGL(k_prj_join, dim3(grid), dim3(kJoinThreads), kJoinSlots * sizeof(uint32_t), s,
+    static_assert(kJoinSlots * 2 == 65536, "two 16-bit counters per LDS word cover every 16-bit key remainder");
+    if (pl.radixBits >= 16)
+        hipLaunchKernelGGL(k_prj_join<true>, dim3(grid), dim3(kJoinThreads), kJoinSlots * sizeof(uint32_t), s,
+                       (const uint32_t*)partR, w.offR, S ? (const uint32_t*)partS : nullptr, w.offS, pl.radixBits, P, (uint32_t)nR,
+                       (uint32_t)(S ? nS : 1), ctr);
+    else
+        hipLaunchKernelGGL(k_prj_join<false>, dim3(grid), dim3(kJoinThreads), kJoinSlots * sizeof(uint32_t), s,
                        (const uint32_t*)partR, w.offR, S ? (const uint32_t*)partS : nullptr, w.offS, pl.radixBits, P, (uint32_t)nR,
                        (uint32_t)(S ? nS : 1), ctr);
 }

@@ -251,6 +251,16 @@ def test_prj_ragged_skewed_and_r_only(ctx):
     got = ctx.run("prj", R1, S1, radixBits=8)
     assert got["totalMatches"] == want["matches"] == oracle.true_cardinality(R1, S1)
     assert got["prjChecksum"] == want["checksum"]
+    # radixBits 16 = the direct-addressed counter join: heavy duplicates inside one partition (counters well above 1),
+    # a partition of exactly 65535 R tuples (the counters' limit) and one of 65536 (falls back to the hash table)
+    for m in (65535, 65536, 40000):
+        R2 = (rng.integers(0, 300, size=m, dtype=np.uint64) << np.uint64(16)) | np.uint64(0x1234)
+        S2 = (rng.integers(0, 400, size=m + 11, dtype=np.uint64) << np.uint64(16)) | np.uint64(0x1234)
+        R2 = np.concatenate([R2, oracle.generate_data("shuffle", 1 << 16)])          # plus ordinary partitions
+        want = oracle.prj_join(R2, S2, 16)
+        got = ctx.run("prj", R2, S2, radixBits=16)
+        assert got["totalMatches"] == want["matches"] == oracle.true_cardinality(R2, S2), m
+        assert got["prjChecksum"] == want["checksum"], m
     # R-side only (what the fork's PRO actually runs): checksum, no matches
     got = ctx.run("prj", R, None, radixBits=14)
     assert got["totalMatches"] == 0 and got["prjChecksum"] == oracle.prj_join(R, None, 14)["checksum"]
