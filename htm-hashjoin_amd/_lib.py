@@ -48,7 +48,7 @@ class hj_result(C.Structure):
         + [(n, C.c_double) for n in (
             "clear_us", "build_us", "probe_us", "partition_us", "join_us", "total_us", "h2d_us")]
         + [("buildDeferred", C.c_uint64), ("buildPhaseA_us", C.c_double), ("algoUsed", C.c_uint32),
-           ("reserved0", C.c_uint32), ("reserved", C.c_uint64 * 1)]
+           ("reserved0", C.c_uint32), ("foreignTuples", C.c_uint64)]
     )
 
     def as_dict(self):
@@ -82,6 +82,7 @@ def _declare(lib):
         "hj_shard_scatter_dev": ([vp, vp, u64, u32, u32, vp, vp], i32),
         "hj_build_keys_dev": ([vp, vp, u64, u32, u64], i32),
         "hj_probe_keys_dev": ([vp, vp, u64], i32),
+        "hj_set_shard_check": ([vp, u32, u32, u32], i32),
         "hj_dev_alloc": ([vp, u64, P(vp)], i32),
         "hj_dev_free": ([vp, vp], i32),
         "hj_copy_h2d": ([vp, vp, vp, u64], i32),

@@ -28,6 +28,7 @@ struct hj_ctx {
     uint64_t tableCapSlots = 0;   // allocated slots incl. slack
     uint64_t tableSize = 0;       // live table (2*rSize) of the last build
     uint32_t hshift = 0;             // home-slot shift of the current table (hj_device.h); 0 unless it is a radix shard
+    ShardCheck sc{0, 0, 0, 0};       // hj_set_shard_check; mask 0 = off
     uint64_t rSize = 0, sSize = 0;
     bool built = false;
     // ownership build (variant 2)
@@ -302,14 +303,14 @@ static int build_common(hj_ctx* c, const void* d, bool key32, uint64_t n, uint32
     c->algoUsed = c->params.algo == HJ_ALGO_AUTO ? (uint32_t)HJ_ALGO_ATOMIC : c->params.algo;
     if (variant == 2) {
         if ((rc = record(c, EV_BUILD0))) return rc;
-        launch_build_own(d, key32, n, hshift, c->table, tableSize, probe_len(c->params), idxBase, c->ownerBuf,
+        launch_build_own(d, key32, n, hshift, c->table, tableSize, probe_len(c->params), idxBase, c->sc, c->ownerBuf,
                          c->queueBuf, c->queueCount, c->dCtr, c->ev[EV_BUILD_A], c->stream);
         c->evSet[EV_BUILD_A] = true;
     } else {
         launch_fill_empty(c->table, tableSize + kTableSlack, c->stream);
         launch_set_full_range(tableSize, c->dCtr, c->stream);
         if ((rc = record(c, EV_BUILD0))) return rc;
-        if (n) launch_build_atomic_min(d, key32, n, c->table, tableSize, hshift, probe_len(c->params), idxBase, c->dCtr, c->stream);
+        if (n) launch_build_atomic_min(d, key32, n, c->table, tableSize, hshift, probe_len(c->params), idxBase, c->sc, c->dCtr, c->stream);
     }
     if ((rc = record(c, EV_BUILD1))) return rc;
     HJ_HIP(c, hipGetLastError());
@@ -345,7 +346,7 @@ int hj_probe_dev(hj_ctx* c, const uint64_t* dS, uint64_t sSize)
     HJ_HIP(c, hipSetDevice(c->device));
     int rc;
     if ((rc = record(c, EV_PROBE0))) return rc;
-    if (sSize) launch_probe(dS, false, sSize, c->table, c->tableSize, c->hshift, probe_len(c->params), c->dCtr, c->stream);
+    if (sSize) launch_probe(dS, false, sSize, c->table, c->tableSize, c->hshift, probe_len(c->params), c->sc, c->dCtr, c->stream);
     if ((rc = record(c, EV_PROBE1))) return rc;
     HJ_HIP(c, hipGetLastError());
     c->sSize += sSize;
@@ -359,7 +360,7 @@ int hj_probe_keys_dev(hj_ctx* c, const uint32_t* dKeys, uint64_t n)
     HJ_HIP(c, hipSetDevice(c->device));
     int rc;
     if ((rc = record(c, EV_PROBE0))) return rc;
-    if (n) launch_probe(dKeys, true, n, c->table, c->tableSize, c->hshift, probe_len(c->params), c->dCtr, c->stream);
+    if (n) launch_probe(dKeys, true, n, c->table, c->tableSize, c->hshift, probe_len(c->params), c->sc, c->dCtr, c->stream);
     if ((rc = record(c, EV_PROBE1))) return rc;
     HJ_HIP(c, hipGetLastError());
     c->sSize += n;
@@ -472,6 +473,7 @@ int hj_fetch_result(hj_ctx* c, hj_result* out)
     }
     out->h2d_us = c->h2d_us;
     out->algoUsed = c->algoUsed;
+    out->foreignTuples = k.foreign;
     if (k.badKeys) return fail(c, HJ_ERR_KEY_RANGE, "input holds tuples with payload bits set or value 0");
     return HJ_OK;
 }
@@ -513,6 +515,16 @@ int hj_run(hj_ctx* c, const hj_params* params, const uint64_t* relR, uint64_t rS
 }
 
 // ---- shard helpers -----------------------------------------------------------
+int hj_set_shard_check(hj_ctx* c, uint32_t nShards, uint32_t mode, uint32_t shardId)
+{
+    if (!c) return HJ_ERR_INVALID;
+    if (nShards == 0) { c->sc = ShardCheck{0, 0, 0, 0}; return HJ_OK; }
+    if (!is_pow2(nShards) || nShards > 64 || shardId >= nShards || (mode & 0xFFu) > 31 || (mode >> 9) != 0)
+        return fail(c, HJ_ERR_INVALID, "hj_set_shard_check: nShards a power of two <= 64, shardId < nShards, mode as for hj_shard_histogram_dev");
+    c->sc = ShardCheck{nShards - 1, mode & 0xFFu, (mode >> 8) & 1u, shardId};
+    return HJ_OK;
+}
+
 static int shard_check(hj_ctx* c, const char* who, uint64_t n, uint32_t nShards, uint32_t mode)
 {
     if (!is_pow2(nShards) || nShards > 64) return fail(c, HJ_ERR_INVALID, who);

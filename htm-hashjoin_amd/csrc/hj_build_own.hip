@@ -99,7 +99,7 @@ constexpr int kQCap = 128;                        // per-wavefront retry queue e
 template <bool KEY32, int ABL = 0>
 __global__ void __launch_bounds__(kOwnThreads, 4)
 k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
-            uint64_t* __restrict__ table, uint64_t mask, uint32_t hshift, uint32_t probeLen, uint64_t idxBase,
+            uint64_t* __restrict__ table, uint64_t mask, uint32_t hshift, uint32_t probeLen, uint64_t idxBase, ShardCheck sc,
             unsigned int* __restrict__ owner, DeferredEntry* __restrict__ queue,
             unsigned long long* __restrict__ queueCount, Counters* __restrict__ ctr)
 {
@@ -130,7 +130,7 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
     uint32_t wb = 0;                 // window = table blocks [wb, wb + kWinBlocks)
     bool haveWin = false;            // false until the first tile with a valid tuple
     unsigned long long dropSum = 0, inSum = 0;
-    uint32_t drops = 0, bad = 0, deferred = 0;
+    uint32_t drops = 0, bad = 0, deferred = 0, foreign = 0;
     uint32_t usedLo = 0xFFFFFFFFu, usedHi1 = 0;   // blocks this thread claimed or deferred into
     uint32_t ownedMask = 0;          // bit r: ring block r is mine (refreshed per tile)
     uint32_t qCount = 0;             // entries in this wavefront's retry queue (wave-uniform)
@@ -251,6 +251,7 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
             const bool ok = in & okKey;
             inSum += in ? (unsigned long long)pack64(khi[j], klo[j]) : 0ull;
             bad += (in & !okKey) ? 1u : 0u;
+            foreign += (in & is_foreign(klo[j], sc)) ? 1u : 0u;          // shard check (off: never)
             liveMask |= ok ? (1u << j) : 0u;
             const uint32_t hb = ((klo[j] >> hshift) & mask32) >> kBlkShift;
             myMin = (ok & (hb < myMin)) ? hb : myMin;
@@ -395,7 +396,7 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
         }
     }
     // counters: one atomic per wavefront
-    unsigned long long c0 = drops, c3 = bad, c4 = deferred;
+    unsigned long long c0 = drops, c3 = bad | ((unsigned long long)foreign << 32), c4 = deferred;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         c0 += __shfl_down(c0, off, 64);
@@ -415,7 +416,8 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
         if (c0) atomicAdd(&ctr->conflicts, c0);
         if (dropSum) atomicAdd(&ctr->conflictSum, dropSum);
         if (inSum) atomicAdd(&ctr->inputSum, inSum);
-        if (c3) atomicAdd(&ctr->badKeys, c3);
+        if (c3 & 0xFFFFFFFFull) atomicAdd(&ctr->badKeys, c3 & 0xFFFFFFFFull);
+        if (c3 >> 32) atomicAdd(&ctr->foreign, c3 >> 32);
         if (c4) atomicAdd(&ctr->deferred, c4);
         if (hi1) { atomicMax(&ctr->usedLoInv, (unsigned long long)loInv); atomicMax(&ctr->usedHi1, (unsigned long long)hi1); }
     }
@@ -566,7 +568,7 @@ void launch_sample_locality(const void* R, bool key32, uint64_t n, uint64_t tabl
 }
 
 void launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshift, uint64_t* table,
-                      uint64_t tableSize, uint32_t probeLen, uint64_t idxBase, void* ownerBuf, void* queueBuf,
+                      uint64_t tableSize, uint32_t probeLen, uint64_t idxBase, ShardCheck sc, void* ownerBuf, void* queueBuf,
                       unsigned long long* queueCount, Counters* ctr, hipEvent_t evPhaseA, hipStream_t s)
 {
     static bool attrSet = false;
@@ -596,7 +598,7 @@ void launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshift, ui
     const unsigned grid = (unsigned)((n + chunkLen - 1) / chunkLen);
     if (key32)
         hipLaunchKernelGGL(k_build_own<true>, dim3(grid), dim3(kOwnThreads), kWinSlots * sizeof(uint64_t), s,
-                           R, n, chunkLen, table, tableSize - 1, hshift, probeLen, idxBase,
+                           R, n, chunkLen, table, tableSize - 1, hshift, probeLen, idxBase, sc,
                            static_cast<unsigned int*>(ownerBuf), static_cast<DeferredEntry*>(queueBuf), queueCount, ctr);
     else {
         // timing-only ablations (results wrong by construction), selected by HJ_OWN_ABLATE
@@ -604,7 +606,7 @@ void launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshift, ui
         if (abl < 0) { const char* e = getenv("HJ_OWN_ABLATE"); abl = e ? atoi(e) : 0; }
 #define HJ_OWN_LAUNCH(A)                                                                                          \
         hipLaunchKernelGGL((k_build_own<false, A>), dim3(grid), dim3(kOwnThreads), kWinSlots * sizeof(uint64_t), s, \
-                           R, n, chunkLen, table, tableSize - 1, hshift, probeLen, idxBase,                                \
+                           R, n, chunkLen, table, tableSize - 1, hshift, probeLen, idxBase, sc,                            \
                            static_cast<unsigned int*>(ownerBuf), static_cast<DeferredEntry*>(queueBuf), queueCount, ctr)
         switch (abl) {
             case 1: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(1); break;

@@ -20,6 +20,12 @@ constexpr uint32_t kTableSlack = 16;
 // the whole key.
 __host__ __device__ inline uint64_t home_slot(uint32_t key, uint32_t hshift, uint64_t mask) { return (uint64_t)(key >> hshift) & mask; }
 
+// Optional shard-membership check riding on build and probe (hj_set_shard_check): a tuple is "foreign" when its
+// destination digit ((key - bias) >> shift) & mask differs from id. mask = 0 (and id = 0) switches it off at no
+// cost in branches: every tuple's digit is then 0.
+struct ShardCheck { uint32_t mask, shift, bias, id; };
+__host__ __device__ inline bool is_foreign(uint32_t key, const ShardCheck& sc) { return (((key - sc.bias) >> sc.shift) & sc.mask) != sc.id; }
+
 constexpr int kBlock = 256;          // 4 wavefronts of 64
 constexpr int kWave = 64;
 
@@ -44,7 +50,7 @@ struct Counters {
     // [validLo, validHiEx + 512) hold defined values.
     unsigned long long usedLoInv, usedHi1;
     unsigned long long validLo, validHiEx;
-    unsigned long long spare[1];
+    unsigned long long foreign;      // tuples of the build / probe inputs that fail the shard check (ShardCheck)
 };
 
 // ---- launch wrappers (defined in hj_kernels.hip) ---------------------------
@@ -52,9 +58,9 @@ struct Counters {
 // or bare 32-bit keys (key32 = true; what the multi-GPU exchange delivers). Index of element i = idxBase + i.
 void launch_fill_empty(uint64_t* table, uint64_t nSlots, hipStream_t s);
 void launch_build_atomic_min(const void* R, bool key32, uint64_t n, uint64_t* table, uint64_t tableSize, uint32_t hshift,
-                             uint32_t probeLen, uint64_t idxBase, Counters* ctr, hipStream_t s);
+                             uint32_t probeLen, uint64_t idxBase, ShardCheck sc, Counters* ctr, hipStream_t s);
 void launch_probe(const void* S, bool key32, uint64_t n, const uint64_t* table, uint64_t tableSize, uint32_t hshift,
-                  uint32_t probeLen, Counters* ctr, hipStream_t s);
+                  uint32_t probeLen, ShardCheck sc, Counters* ctr, hipStream_t s);
 void launch_table_sums(const uint64_t* table, uint64_t tableSize, uint64_t halfSlots, Counters* ctr, hipStream_t s);
 // Marks the whole table valid (variant 1 clears and may touch all of it).
 void launch_set_full_range(uint64_t tableSize, Counters* ctr, hipStream_t s);
@@ -75,7 +81,7 @@ void launch_sample_locality(const void* R, bool key32, uint64_t n, uint64_t tabl
 // phase A (LDS window) -> clear of unowned blocks -> phase B (deferred tuples).
 // Writes every table slot exactly once: no separate launch_fill_empty needed.
 void launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshift, uint64_t* table,
-                      uint64_t tableSize, uint32_t probeLen, uint64_t idxBase, void* ownerBuf, void* queueBuf,
+                      uint64_t tableSize, uint32_t probeLen, uint64_t idxBase, ShardCheck sc, void* ownerBuf, void* queueBuf,
                       unsigned long long* queueCount, Counters* ctr, hipEvent_t evPhaseA, hipStream_t s);
 
 // ---- PRJ (defined in hj_prj.hip) -------------------------------------------

@@ -105,11 +105,12 @@ __device__ __forceinline__ void insert_priority(uint64_t* __restrict__ table, ui
 
 // t = the element zero-extended to 64 bits (a tuple as it is, or a bare key)
 __device__ __forceinline__ void build_one(uint64_t t, uint64_t idx, uint64_t* __restrict__ table,
-                                          uint64_t mask, uint32_t hshift, uint32_t probeLen,
+                                          uint64_t mask, uint32_t hshift, uint32_t probeLen, const ShardCheck& sc,
                                           unsigned long long& drops, unsigned long long& dropSum,
                                           unsigned long long& inSum, unsigned long long& bad)
 {
     inSum += t;
+    bad += is_foreign((uint32_t)t, sc) ? (1ull << 32) : 0ull;      // foreign tuples ride in the high half of `bad`
     if ((t >> 32) != 0 || t == 0) { bad += 1; return; }
     const uint64_t mine = (idx << 32) | t;
     insert_priority(table, mask, hshift, probeLen, mine, home_slot((uint32_t)t, hshift, mask), probeLen, drops, dropSum);
@@ -120,13 +121,13 @@ __device__ __forceinline__ void build_one(uint64_t t, uint64_t idx, uint64_t* __
 template <bool KEY32>
 __global__ void __launch_bounds__(kBlock)
 k_build_atomic_min(const void* __restrict__ Rv, uint64_t n, uint64_t* __restrict__ table,
-                   uint64_t mask, uint32_t hshift, uint32_t probeLen, uint64_t idxBase, Counters* __restrict__ ctr)
+                   uint64_t mask, uint32_t hshift, uint32_t probeLen, uint64_t idxBase, ShardCheck sc, Counters* __restrict__ ctr)
 {
     unsigned long long drops = 0, dropSum = 0, inSum = 0, bad = 0;
     if constexpr (KEY32) {
         const uint32_t* K = static_cast<const uint32_t*>(Rv);
         for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock)
-            build_one(K[i], idxBase + i, table, mask, hshift, probeLen, drops, dropSum, inSum, bad);
+            build_one(K[i], idxBase + i, table, mask, hshift, probeLen, sc, drops, dropSum, inSum, bad);
     } else {
         const uint64_t* R = static_cast<const uint64_t*>(Rv);
         const uint64_t head = (n > 0 && (reinterpret_cast<uintptr_t>(R) & 8)) ? 1 : 0;
@@ -135,30 +136,31 @@ k_build_atomic_min(const void* __restrict__ Rv, uint64_t n, uint64_t* __restrict
         for (uint64_t v = (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (uint64_t)gridDim.x * kBlock) {
             const ulonglong2 t = R2[v];
             const uint64_t i = head + 2 * v;
-            build_one(t.x, idxBase + i, table, mask, hshift, probeLen, drops, dropSum, inSum, bad);
-            build_one(t.y, idxBase + i + 1, table, mask, hshift, probeLen, drops, dropSum, inSum, bad);
+            build_one(t.x, idxBase + i, table, mask, hshift, probeLen, sc, drops, dropSum, inSum, bad);
+            build_one(t.y, idxBase + i + 1, table, mask, hshift, probeLen, sc, drops, dropSum, inSum, bad);
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) {
-            if (head) build_one(R[0], idxBase, table, mask, hshift, probeLen, drops, dropSum, inSum, bad);
+            if (head) build_one(R[0], idxBase, table, mask, hshift, probeLen, sc, drops, dropSum, inSum, bad);
             const uint64_t tail = head + 2 * nv;
-            if (tail < n) build_one(R[tail], idxBase + tail, table, mask, hshift, probeLen, drops, dropSum, inSum, bad);
+            if (tail < n) build_one(R[tail], idxBase + tail, table, mask, hshift, probeLen, sc, drops, dropSum, inSum, bad);
         }
     }
     flush_counter(&ctr->conflicts, drops);
     flush_counter(&ctr->conflictSum, dropSum);
     flush_counter(&ctr->inputSum, inSum);
-    flush_counter(&ctr->badKeys, bad);
+    flush_counter(&ctr->badKeys, bad & 0xFFFFFFFFull);
+    flush_counter(&ctr->foreign, bad >> 32);
 }
 
 void launch_build_atomic_min(const void* R, bool key32, uint64_t n, uint64_t* table, uint64_t tableSize, uint32_t hshift,
-                             uint32_t probeLen, uint64_t idxBase, Counters* ctr, hipStream_t s)
+                             uint32_t probeLen, uint64_t idxBase, ShardCheck sc, Counters* ctr, hipStream_t s)
 {
     if (key32)
         hipLaunchKernelGGL(k_build_atomic_min<true>, dim3(grid_for(n + 1, kBlock)), dim3(kBlock), 0, s,
-                           R, n, table, tableSize - 1, hshift, probeLen, idxBase, ctr);
+                           R, n, table, tableSize - 1, hshift, probeLen, idxBase, sc, ctr);
     else
         hipLaunchKernelGGL(k_build_atomic_min<false>, dim3(grid_for(n / 2 + 1, kBlock)), dim3(kBlock), 0, s,
-                           R, n, table, tableSize - 1, hshift, probeLen, idxBase, ctr);
+                           R, n, table, tableSize - 1, hshift, probeLen, idxBase, sc, ctr);
 }
 
 // ---------------------------------------------------------------------------
@@ -229,11 +231,12 @@ __device__ __forceinline__ uint32_t count_window(const Window& w)
 template <bool KEY32>
 __global__ void __launch_bounds__(kBlock)
 k_probe(const void* __restrict__ Sv, uint64_t n, const uint64_t* __restrict__ table, uint64_t mask,
-        uint32_t hshift, uint32_t probeLen, Counters* __restrict__ ctr)
+        uint32_t hshift, uint32_t probeLen, ShardCheck sc, Counters* __restrict__ ctr)
 {
     using Elem = typename std::conditional<KEY32, uint32_t, uint64_t>::type;
     constexpr uint64_t EPV = 16 / sizeof(Elem);
     unsigned long long matches = 0;
+    uint32_t foreign = 0;                                          // shard check (off: always 0)
     const uint64_t validLo = ctr->validLo, validHiEx = ctr->validHiEx;
     const uint64_t dummy = validLo < mask ? validLo : 0;          // any in-table slot; this one is in cache
     const Elem* S = static_cast<const Elem*>(Sv);
@@ -244,6 +247,7 @@ k_probe(const void* __restrict__ Sv, uint64_t n, const uint64_t* __restrict__ ta
     for (uint64_t v = (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (uint64_t)gridDim.x * kBlock) {
         const uint4 t = S4[v];
         if constexpr (KEY32) {
+            foreign += (uint32_t)is_foreign(t.x, sc) + (uint32_t)is_foreign(t.y, sc) + (uint32_t)is_foreign(t.z, sc) + (uint32_t)is_foreign(t.w, sc);
             if (probeLen == 4) {
                 const Window w0 = load_window(t.x, table, mask, hshift, validLo, validHiEx, dummy);
                 const Window w1 = load_window(t.y, table, mask, hshift, validLo, validHiEx, dummy);
@@ -257,26 +261,28 @@ k_probe(const void* __restrict__ Sv, uint64_t n, const uint64_t* __restrict__ ta
                 matches += probe_one(t.w, table, mask, hshift, probeLen, validLo, validHiEx);
             }
         } else {
+            foreign += (uint32_t)is_foreign(t.x, sc) + (uint32_t)is_foreign(t.z, sc);
             matches += probe_one(((uint64_t)t.y << 32) | t.x, table, mask, hshift, probeLen, validLo, validHiEx);
             matches += probe_one(((uint64_t)t.w << 32) | t.z, table, mask, hshift, probeLen, validLo, validHiEx);
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        for (uint64_t i = 0; i < head; ++i) matches += probe_one(S[i], table, mask, hshift, probeLen, validLo, validHiEx);
-        for (uint64_t i = head + nv * EPV; i < n; ++i) matches += probe_one(S[i], table, mask, hshift, probeLen, validLo, validHiEx);
+        for (uint64_t i = 0; i < head; ++i) { matches += probe_one(S[i], table, mask, hshift, probeLen, validLo, validHiEx); foreign += is_foreign((uint32_t)S[i], sc); }
+        for (uint64_t i = head + nv * EPV; i < n; ++i) { matches += probe_one(S[i], table, mask, hshift, probeLen, validLo, validHiEx); foreign += is_foreign((uint32_t)S[i], sc); }
     }
     flush_counter(&ctr->matches, matches);
+    flush_counter(&ctr->foreign, foreign);
 }
 
 void launch_probe(const void* S, bool key32, uint64_t n, const uint64_t* table, uint64_t tableSize, uint32_t hshift,
-                  uint32_t probeLen, Counters* ctr, hipStream_t s)
+                  uint32_t probeLen, ShardCheck sc, Counters* ctr, hipStream_t s)
 {
     if (key32)
         hipLaunchKernelGGL(k_probe<true>, dim3(grid_for(n / 4 + 1, kBlock)), dim3(kBlock), 0, s,
-                           S, n, table, tableSize - 1, hshift, probeLen, ctr);
+                           S, n, table, tableSize - 1, hshift, probeLen, sc, ctr);
     else
         hipLaunchKernelGGL(k_probe<false>, dim3(grid_for(n / 2 + 1, kBlock)), dim3(kBlock), 0, s,
-                           S, n, table, tableSize - 1, hshift, probeLen, ctr);
+                           S, n, table, tableSize - 1, hshift, probeLen, sc, ctr);
 }
 
 // ---------------------------------------------------------------------------

@@ -168,6 +168,10 @@ class HashJoinContext:
     def probe_keys(self, d_keys, n):
         self._check(lib.hj_probe_keys_dev(self._h, C.c_void_p(d_keys), n))
 
+    def set_shard_check(self, n_shards, mode=0, shard_id=0):
+        """later builds/probes also count tuples whose destination is another shard (result["foreignTuples"]); 0 = off"""
+        self._check(lib.hj_set_shard_check(self._h, n_shards, mode, shard_id))
+
 
 def _operator(algo, relR, rSize, relS, sSize, device, **kw):
     relR = np.asarray(relR, dtype=np.uint64)[:rSize]

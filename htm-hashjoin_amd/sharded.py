@@ -102,6 +102,13 @@ class HipShardEngine:
     def probe_tuples(self, s_tuples):
         self.ctx.probe(s_tuples.data_ptr(), s_tuples.numel())
 
+    def set_check(self, n_shards, mode=0, shard_id=0):
+        self.ctx.set_shard_check(n_shards, mode, shard_id)
+
+    def foreign(self):
+        """tuples of the last build + probes whose destination was another shard (waits for the stream)"""
+        return self.ctx.fetch()["foreignTuples"]
+
     def finish(self):
         self.ctx.checksums()
         r = self.ctx.fetch()
@@ -134,6 +141,7 @@ class ShardedJoin:
         self.shift = 0                  # home-slot shift of the local tables: log2 G for the low-bit split
         self.last = {}
         self._keep = None
+        self._in_place_hint = False     # the previous step found every tuple already on its rank
 
     def _all_reduce_scalar(self, v, op):
         if self.dist is None or self.world == 1:
@@ -211,6 +219,27 @@ class ShardedJoin:
                 works = self.dist.batch_isend_irecv(ops)
         return out, works
 
+    def _try_in_place(self, r_local, s_local, table_size):
+        """Optimistic step after one that moved nothing: join the pieces in place with the shard check riding on the
+        build and probe kernels (no histogram pass, no split); accept if no rank saw a foreign tuple, else report
+        False and let the caller run the full path (the table is rebuilt there)."""
+        if not (self._in_place_hint and self.world > 1 and self.shift == 0 and table_size == 2 * r_local.numel()):
+            return False
+        e = self.e
+        e.set_check(self.world, self.mode, self.rank)
+        e.reserve(table_size, r_local.numel(), s_local.numel())
+        e.build_tuples(r_local)
+        e.probe_tuples(s_local)
+        foreign = e.foreign()
+        e.set_check(0)
+        if self._all_reduce_scalar(foreign, "SUM") != 0:
+            self._in_place_hint = False
+            return False
+        self.last = {"sent_r": 0, "sent_s": 0, "recv_r": r_local.numel(), "recv_s": s_local.numel(),
+                     "split": f"high key bits (range split, digit at bit {self.mode & 0xFF}); pieces joined in place, "
+                              "membership checked inside build and probe"}
+        return True
+
     def step(self, r_local, s_local, table_size):
         """One build+probe over this rank's pieces (rank g holds the g-th contiguous piece of each relation).
         Everything is enqueued; call result() to sync. The exchange of R overlaps the split of S, and the
@@ -221,6 +250,8 @@ class ShardedJoin:
         self._keep = None
         if self.mode is None:
             self._decide_split(r_local, s_local)
+        if self._try_in_place(r_local, s_local, table_size):
+            return
         cnt_r = e.histogram(r_local, self.world, self.mode)
         cnt_s = e.histogram(s_local, self.world, self.mode)
         send_r, send_s, recv_r, recv_s = self._exchange_counts(cnt_r, cnt_s)
@@ -235,6 +266,7 @@ class ShardedJoin:
             e.probe_tuples(s_local)
             self.last = {"sent_r": 0, "sent_s": 0, "recv_r": r_local.numel(), "recv_s": s_local.numel(),
                          "split": split_name + "; no tuple had to move: pieces joined in place"}
+            self._in_place_hint = True          # next step: try it straight away, checked inside build and probe
             return
         out_r = e.scatter(r_local, self.world, cnt_r, self.mode)                # keys, grouped by destination
         got_r, work_r = self._exchange_async(out_r, send_r, recv_r)

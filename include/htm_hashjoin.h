@@ -108,7 +108,8 @@ typedef struct {
     uint32_t algoUsed;        /* hj_algo that produced this result (differs from
                                  hj_params.algo only for HJ_ALGO_AUTO)               */
     uint32_t reserved0;
-    uint64_t reserved[1];
+    uint64_t foreignTuples;   /* hj_set_shard_check: build + probe tuples whose
+                                 destination is another shard (0 when the check is off) */
 } hj_result;
 
 typedef struct hj_ctx hj_ctx;
@@ -203,6 +204,12 @@ int hj_shard_scatter_dev(hj_ctx *ctx, const uint64_t *dIn, uint64_t n,
 int hj_build_keys_dev(hj_ctx *ctx, const uint32_t *dKeys, uint64_t n,
                       uint32_t homeShift, uint64_t tableSize);
 int hj_probe_keys_dev(hj_ctx *ctx, const uint32_t *dKeys, uint64_t n);
+/* Optimistic joining in place: under a range split the pieces a rank holds are often already its shards. While a
+ * check is set (nShards > 0), every later build and probe on this context also counts, at no extra pass over the
+ * data, the tuples whose destination under (nShards, mode) is NOT shardId -> hj_result.foreignTuples. A caller
+ * joins its pieces in place with hj_build_dev / hj_probe_dev and takes the result if the count is 0 on every
+ * rank, else redoes the step with split + exchange. nShards = 0 switches the check off. */
+int hj_set_shard_check(hj_ctx *ctx, uint32_t nShards, uint32_t mode, uint32_t shardId);
 
 /* ---- device memory for hosts without a HIP runtime of their own ----------- */
 int hj_dev_alloc(hj_ctx *ctx, uint64_t bytes, void **dptr);

@@ -497,9 +497,38 @@ def test_sharded_join_product_engine_in_process_ranks(world, dist, window, split
         assert got["mode"] == (bits | hj.SHARD_ONE_BASED)
         want = oracle.sharded_reference(R, S, world, digit_shift=bits, one_based=True)
         assert ("in place" in got["exchange"]["split"]) == (expect == "in place")
+        if expect == "in place":      # the second step took the optimistic route: membership checked by the kernels
+            assert "checked inside build and probe" in got["exchange"]["split"]
     for k in want:
         assert got[k] == want[k], (k, got[k], want[k])
     assert all(o["conflicts"] == got["conflicts"] for o in out)           # the all-reduce reached every rank
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_shard_check_counts_foreign_tuples(variant):
+    """hj_set_shard_check: builds and probes count the tuples whose destination is another shard, on tuples and on keys,
+    in both build kernels; off again afterwards."""
+    n, G = 1 << 16, 4
+    mode = 14 | hj.SHARD_ONE_BASED
+    R = oracle.generate_data("uniform", n, n, 16)
+    S = oracle.generate_data("sorted", n)
+    dest = lambda k: (((k - np.uint64(1)) >> np.uint64(14)) & np.uint64(G - 1))          # noqa: E731
+    with hj.HashJoinContext(0) as c:
+        dR = c.dev_alloc(n * 8); dS = c.dev_alloc(n * 8 + 16); dK = c.dev_alloc(n * 4 + 16)
+        c.copy_h2d(dR, R); c.copy_h2d(dS + 8, S); c.copy_h2d(dK + 4, S.astype(np.uint32))
+        c.reserve("atomic", n, n, buildVariant=variant)
+        for shard in (0, 3):
+            c.set_shard_check(G, mode, shard)
+            c.build(dR, n); c.probe(dS + 8, n); c.probe_keys(dK + 4, n)
+            got = c.fetch()
+            assert got["foreignTuples"] == int((dest(R) != shard).sum()) + 2 * int((dest(S) != shard).sum())
+        c.set_shard_check(0)
+        c.build(dR, n); c.probe(dS + 8, n)
+        assert c.fetch()["foreignTuples"] == 0
+        with pytest.raises(hj.HashJoinError):
+            c.set_shard_check(3, 0, 0)
+        for p_ in (dR, dS, dK):
+            c.dev_free(p_)
 
 
 def test_shard_split_flags_payload_bits(ctx):

@@ -49,12 +49,30 @@ class OracleShardEngine:
         # position in the receive buffer = insertion order
         self._built = (r_keys.numpy().view(np.uint32).astype(np.uint64), home_shift, table_size)
 
+    _check = None
+
+    def set_check(self, n_shards, mode=0, shard_id=0):
+        self._check = (n_shards, mode, shard_id) if n_shards else None
+
+    def _count_foreign(self, k):
+        if self._check is None:
+            return 0
+        n_shards, mode, shard_id = self._check
+        return int((self._dest(k, n_shards, mode) != shard_id).sum())
+
     def build_tuples(self, r_tuples):
-        self._built = (r_tuples.numpy().view(np.uint64).copy(), 0, 2 * r_tuples.numel())
+        k = r_tuples.numpy().view(np.uint64).copy()
+        self._foreign = self._count_foreign(k)
+        self._built = (k, 0, 2 * r_tuples.numel())
 
     def probe_tuples(self, s_tuples):
         keys, home_shift, table_size = self._built
-        self._res = oracle.build_probe_seq_ts(keys, s_tuples.numpy().view(np.uint64).copy(), table_size, home_shift)
+        k = s_tuples.numpy().view(np.uint64).copy()
+        self._foreign += self._count_foreign(k)
+        self._res = oracle.build_probe_seq_ts(keys, k, table_size, home_shift)
+
+    def foreign(self):
+        return self._foreign
 
     def probe(self, s_keys):
         keys, home_shift, table_size = self._built
@@ -74,7 +92,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, dist_name, window, n_local, out, split="low"):
+def _worker(rank, world, port, dist_name, window, n_local, out, split="low", second=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import htm_hashjoin_amd as hj
@@ -87,6 +105,13 @@ def _worker(rank, world, port, dist_name, window, n_local, out, split="low"):
     job = ShardedJoin(OracleShardEngine(), torch, dist, rank, world, split=split)
     job.max_msg_tuples = 700            # force the exchange into several messages per peer
     job.step(r_local, s_local, 2 * n_local)
+    if second:                                       # a second step: the optimistic in-place attempt, or its fallback
+        in_place_first = "in place" in job.last["split"]
+        if second == "moved" and rank == 0:
+            r_local[0] = n                           # the largest key belongs to the last rank: one tuple has to travel
+        job.step(r_local, s_local, 2 * n_local)
+        assert in_place_first
+        assert ("checked inside build and probe" in job.last["split"]) == (second == "same"), job.last
     res = job.result()
     if rank == 0:
         d = {k: res[k] for k in ("conflicts", "totalMatches", "inputSum", "tableSumFull", "conflictSum")}
@@ -150,6 +175,30 @@ def test_range_split(split, dist_name, window, expect_high):
         assert mode == 0
         want = oracle.sharded_reference(R, S, world)
     assert got == want
+
+
+@pytest.mark.parametrize("second", ["same", "moved"])
+def test_optimistic_in_place_step_and_its_fallback(second):
+    """After a step that moved nothing the next one joins in place straight away, the shard check riding on build and
+    probe; if a tuple has meanwhile appeared that belongs elsewhere, every rank sees the non-zero count and the step is
+    redone with split and exchange. Totals equal the sharded reference of the data of the second step either way."""
+    world, n_local = 2, 1 << 12
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, PORT[0], "sorted", 16, n_local, q, "auto", second)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n = n_local * world
+    R = oracle.generate_data("sorted", n); S = oracle.generate_data("sorted", n)
+    if second == "moved":
+        R[0] = n
+    assert got.pop("mode") == (12 | 0x100)
+    assert (got.pop("sent") > 0) == (second == "moved")
+    assert got == oracle.sharded_reference(R, S, world, digit_shift=12, one_based=True)
 
 
 def test_range_split_nothing_moves_joins_in_place():
