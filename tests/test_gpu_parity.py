@@ -504,6 +504,59 @@ def test_sharded_join_product_engine_in_process_ranks(world, dist, window, split
     assert all(o["conflicts"] == got["conflicts"] for o in out)           # the all-reduce reached every rank
 
 
+def test_randomised_differential_keys_and_tuples():
+    """Seeded random configurations -- table size, home shift, probe length, build variant, duplicate density, arrival
+    order, element format (tuples / bare keys), odd buffer offsets -- through the split device API against the
+    sequential oracle: whole table and all counters."""
+    rng = np.random.default_rng(20241004)
+    for case in range(160):
+        log2t = int(rng.integers(13, 19))                      # table of 2^13 .. 2^18 slots
+        table_size = 1 << log2t
+        n = int(rng.integers(table_size // 8, table_size // 2 + 1))
+        hshift = int(rng.integers(0, 4))
+        probe_len = int(rng.choice([1, 2, 3, 4, 4, 4, 5, 8]))
+        variant = int(rng.integers(1, 3))
+        key32 = bool(rng.integers(0, 2)) or hshift > 0        # tuples have no home shift in the ABI
+        span = int(rng.choice([n // 4 + 1, n, 4 * n, 1 << 31]))
+        keys = rng.integers(1, span + 1, size=n, dtype=np.uint64)
+        order = int(rng.integers(0, 3))
+        if order == 0:
+            keys.sort()
+        elif order == 1:                                       # near-sorted: sorted, then shuffled inside windows of 64
+            keys.sort()
+            for b in range(0, n - 64, 64):
+                rng.shuffle(keys[b:b + 64])
+        keys = (keys << np.uint64(hshift)) | np.uint64(rng.integers(0, 1 << hshift)) if hshift else keys
+        keys &= np.uint64(0xFFFFFFFF)
+        keys[keys == 0] = 1
+        S = np.concatenate([keys[rng.integers(0, n, size=n // 2)], rng.integers(1, 1 << 32, size=n // 3, dtype=np.uint64)])
+        want = oracle.build_probe_seq_ts(keys, S, table_size, hshift, probe_len, want_table=True)
+        with hj.HashJoinContext(0) as c:
+            c.reserve("atomic", table_size // 2, S.size, buildVariant=variant, probeLength=probe_len)
+            offR, offS = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+            if key32:
+                dR = c.dev_alloc(n * 4 + 32); dS = c.dev_alloc(S.size * 4 + 32)
+                c.copy_h2d(dR + 4 * offR, keys.astype(np.uint32)); c.copy_h2d(dS + 4 * offS, S.astype(np.uint32))
+                c.build_keys(dR + 4 * offR, n, hshift, table_size)
+                c.probe_keys(dS + 4 * offS, S.size)
+            else:
+                if n * 2 != table_size:                        # hj_build_dev fixes the table at 2 * rSize, rSize a power of two
+                    n = table_size // 2
+                    keys = np.resize(keys, n); S = S[: max(1, S.size)]
+                    want = oracle.build_probe_seq_ts(keys, S, table_size, 0, probe_len, want_table=True)
+                dR = c.dev_alloc(n * 8 + 32); dS = c.dev_alloc(S.size * 8 + 32)
+                c.copy_h2d(dR + 8 * (offR & 1), keys); c.copy_h2d(dS + 8 * (offS & 1), S)
+                c.build(dR + 8 * (offR & 1), n)
+                c.probe(dS + 8 * (offS & 1), S.size)
+            c.checksums()
+            got = c.fetch()
+            tag = (case, log2t, n, hshift, probe_len, variant, key32, span, order)
+            for k in ("conflicts", "totalMatches", "inputSum", "tableSumFull", "conflictSum"):
+                assert got[k] == want[k], (k, got[k], want[k], tag)
+            assert np.array_equal(c.export_table(table_size), want["table"]), tag
+            c.dev_free(dR); c.dev_free(dS)
+
+
 @pytest.mark.parametrize("variant", [1, 2])
 def test_shard_check_counts_foreign_tuples(variant):
     """hj_set_shard_check: builds and probes count the tuples whose destination is another shard, on tuples and on keys,
