@@ -96,7 +96,7 @@ constexpr int kQCap = 128;                        // per-wavefront retry queue e
 //               atomicMin) run on 64 queue entries at a time, so every round is dense regardless of
 //               how long individual probe/displacement chains get.
 // All per-tuple arithmetic is 32-bit: key = low word, slot numbers < 2^32, value = {key, index}.
-template <bool KEY32, int ABL = 0>
+template <bool KEY32, int ABL = 0, bool CHECK = false>
 __global__ void __launch_bounds__(kOwnThreads, 4)
 k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
             uint64_t* __restrict__ table, uint64_t mask, uint32_t hshift, uint32_t probeLen, uint64_t idxBase, ShardCheck sc,
@@ -251,7 +251,7 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
             const bool ok = in & okKey;
             inSum += in ? (unsigned long long)pack64(khi[j], klo[j]) : 0ull;
             bad += (in & !okKey) ? 1u : 0u;
-            foreign += (in & is_foreign(klo[j], sc)) ? 1u : 0u;          // shard check (off: never)
+            if constexpr (CHECK) foreign += (in & is_foreign(klo[j], sc)) ? 1u : 0u;   // shard check: its own instance
             liveMask |= ok ? (1u << j) : 0u;
             const uint32_t hb = ((klo[j] >> hshift) & mask32) >> kBlkShift;
             myMin = (ok & (hb < myMin)) ? hb : myMin;
@@ -596,6 +596,24 @@ void launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshift, ui
     chunkLen = (chunkLen + kOwnTile - 1) / kOwnTile * kOwnTile;
     if (chunkLen < (uint64_t)kOwnTile * 4) chunkLen = (uint64_t)kOwnTile * 4;
     const unsigned grid = (unsigned)((n + chunkLen - 1) / chunkLen);
+    if (sc.mask) {      // shard check requested: the instances that count foreign tuples
+        static bool attrSetC = false;
+        if (!attrSetC) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 0, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<true, 0, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t));
+            attrSetC = true;
+        }
+        if (key32)
+            hipLaunchKernelGGL((k_build_own<true, 0, true>), dim3(grid), dim3(kOwnThreads), kWinSlots * sizeof(uint64_t), s,
+                               R, n, chunkLen, table, tableSize - 1, hshift, probeLen, idxBase, sc,
+                               static_cast<unsigned int*>(ownerBuf), static_cast<DeferredEntry*>(queueBuf), queueCount, ctr);
+        else
+            hipLaunchKernelGGL((k_build_own<false, 0, true>), dim3(grid), dim3(kOwnThreads), kWinSlots * sizeof(uint64_t), s,
+                               R, n, chunkLen, table, tableSize - 1, hshift, probeLen, idxBase, sc,
+                               static_cast<unsigned int*>(ownerBuf), static_cast<DeferredEntry*>(queueBuf), queueCount, ctr);
+    } else
     if (key32)
         hipLaunchKernelGGL(k_build_own<true>, dim3(grid), dim3(kOwnThreads), kWinSlots * sizeof(uint64_t), s,
                            R, n, chunkLen, table, tableSize - 1, hshift, probeLen, idxBase, sc,
