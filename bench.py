@@ -162,6 +162,29 @@ def cpu_baseline(hj, log2n, dist, window):
     }
 
 
+def cpu_baseline_prj(log2n):
+    """The reference's own radix join, mc PRO, compiled from its sources (oracle/_ref/mchashjoins, oracle/Makefile), on
+    the host cores: 2^log2n tuples per relation as in experiments/motivation.sh. In this fork PRO partitions R and S and
+    builds R's tables but the probe is commented out (parallel_radix_join.c:259-276), so its time is a lower bound for
+    a full join. None when the binary is not there (it is built where /root/reference is)."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "mchashjoins")
+    if not os.path.exists(exe):
+        return None
+    n = 1 << log2n
+    threads = min(64, os.cpu_count() or 1)
+    try:
+        out = subprocess.run([exe, "--algo=PRO", f"--nthreads={threads}", f"--r-size={n}", f"--s-size={n}"],
+                             capture_output=True, text=True, timeout=90).stdout
+        us = float(re.search(r"TOTAL-TIME-USECS[^\n]*\n\s*([0-9.]+)", out).group(1))
+    except Exception as e:   # noqa: BLE001 -- a baseline that cannot run is reported as such, never fatal
+        return {"error": repr(e)[:200]}
+    return {"value": 2 * n / us, "unit": "Mtuples/s", "cores": threads, "kind": "reference",
+            "sample": f"mc PRO (partition R and S + build R, probe disabled in the fork), |R|=|S|=2^{log2n} of its own "
+                      f"pk/fk generator, {us / 1e3:.1f} ms; compare other_workloads.prj_local_shuffle_1024"}
+
+
 def main():
     a = parse()
     import torch
@@ -248,9 +271,10 @@ def main():
     del S_dev
     torch.cuda.empty_cache()
 
-    cpu = None
+    cpu = cpu_prj = None
     if not a.no_cpu_baseline:
         cpu = cpu_baseline(hj, min(a.cpu_sample_log2n, a.log2n), a.dist, a.shuffle_range)
+        cpu_prj = cpu_baseline_prj(min(a.cpu_sample_log2n, a.log2n))
 
     line = {
         "metric": "Mtuples/sec build+probe, |R|=|S|=1B uint32, uniform vs local_shuffle",
@@ -263,7 +287,7 @@ def main():
                    "algo": "atomic", "rSize": n, "sSize": n, "dataDistr": a.dist, "shuffleRange": a.shuffle_range},
         "result": {k: main_leg[k] for k in ("conflicts", "totalMatches", "inputSum", "buildVariant",
                                             "buildDeferred", "checks")},
-        "roofline": roofline, "cpu_baseline": cpu, "other_workloads": extra,
+        "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_prj": cpu_prj, "other_workloads": extra,
     }
     print(json.dumps(line), flush=True)
 
