@@ -175,14 +175,17 @@ def cpu_baseline_prj(log2n):
     n = 1 << log2n
     threads = min(64, os.cpu_count() or 1)
     try:
-        out = subprocess.run([exe, "--algo=PRO", f"--nthreads={threads}", f"--r-size={n}", f"--s-size={n}"],
-                             capture_output=True, text=True, timeout=90).stdout
-        us = float(re.search(r"TOTAL-TIME-USECS[^\n]*\n\s*([0-9.]+)", out).group(1))
+        us = None
+        for _ in range(2):       # best of 2: the host share of a GPU box is a noisy place
+            out = subprocess.run([exe, "--algo=PRO", f"--nthreads={threads}", f"--r-size={n}", f"--s-size={n}"],
+                                 capture_output=True, text=True, timeout=90).stdout
+            t = float(re.search(r"TOTAL-TIME-USECS[^\n]*\n\s*([0-9.]+)", out).group(1))
+            us = t if us is None else min(us, t)
     except Exception as e:   # noqa: BLE001 -- a baseline that cannot run is reported as such, never fatal
         return {"error": repr(e)[:200]}
     return {"value": 2 * n / us, "unit": "Mtuples/s", "cores": threads, "kind": "reference",
             "sample": f"mc PRO (partition R and S + build R, probe disabled in the fork), |R|=|S|=2^{log2n} of its own "
-                      f"pk/fk generator, {us / 1e3:.1f} ms; compare other_workloads.prj_local_shuffle_1024"}
+                      f"pk/fk generator, best of 2: {us / 1e3:.1f} ms; compare other_workloads.prj_local_shuffle_1024"}
 
 
 def main():
