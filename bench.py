@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--cpu-sample-log2n", type=int, default=27)
     ap.add_argument("--build-variant", type=int, default=0, help="0 auto, 1 global atomics, 2 LDS window")
     ap.add_argument("--strong", action="store_true", help="N>1: split the N=1 total instead of 2^log2n per GPU")
+    ap.add_argument("--other-split", action="store_true",
+                    help="N>1: also time a few steps with the split that was NOT chosen and report them as other_split")
     ap.add_argument("--split", default="auto", choices=["auto", "low", "high"],
                     help="N>1: destination = low key bits, high key bits (range split), or auto = high when >= 3/4 of "
                          "every rank's tuples stay put under it (sharded.py)")

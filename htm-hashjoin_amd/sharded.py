@@ -367,9 +367,10 @@ def bench_sharded(args, torch, dist, hj, rank, world, local_rank):
     job, dt = timed(args.split, args.steps, args.warmup)
     res = job.result()
     total = 2 * n * world
-    # the same join with the other split, a few steps, for the record (not part of `value`)
+    # the same join with the other split, a few steps, for the record (not part of `value`); on request only: the
+    # default run should not depend on the large point-to-point exchange when the chosen split does not need it
     alt = None
-    if world > 1:
+    if world > 1 and args.other_split:
         other = "high" if job.mode == 0 else "low"
         k = max(1, min(3, args.steps))
         ajob, adt = timed(other, k, 1)
