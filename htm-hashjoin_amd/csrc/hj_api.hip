@@ -241,6 +241,9 @@ int hj_reserve(hj_ctx* c, const hj_params* params, uint64_t rSize, uint64_t sSiz
             c->capWork = c->plan.workspaceBytes;
         }
         if (params->algo == HJ_ALGO_PRJ) return HJ_OK;      // AUTO also needs the open-addressing buffers below
+        // ... when the table join can take this R at all (it wants a power-of-two size, as the reference does);
+        // otherwise AUTO simply is the radix join, which has no such restriction
+        if (!is_pow2(rSize) || rSize > (1ull << 31)) return HJ_OK;
     }
     if (!is_pow2(rSize)) return fail(c, HJ_ERR_INVALID, "hj_reserve: rSize must be a power of two (DataGen.hpp:28, NoCCHashBuild.hpp:36)");
     if (rSize > (1ull << 31)) return fail(c, HJ_ERR_INVALID, "hj_reserve: rSize > 2^31 per device");
@@ -406,9 +409,10 @@ int hj_join_dev(hj_ctx* c, const uint64_t* dR, uint64_t rSize, const uint64_t* d
         // the same question the build asks itself for buildVariant 0, asked once here: with locality the
         // LDS-window build + linear probe wins, without it both of them turn into random HBM accesses
         // and two radix passes are cheaper
-        if (!is_pow2(rSize) || 2 * rSize + kTableSlack > c->tableCapSlots)
-            return fail(c, HJ_ERR_STATE, "hj_join_dev: hj_reserve() not called for this rSize");
         HJ_HIP(c, hipSetDevice(c->device));
+        if (!is_pow2(rSize) || rSize > (1ull << 31)) return hj_prj_join_dev(c, dR, rSize, dS, sSize);   // see hj_reserve
+        if (2 * rSize + kTableSlack > c->tableCapSlots)
+            return fail(c, HJ_ERR_STATE, "hj_join_dev: hj_reserve() not called for this rSize");
         bool local = false;
         const bool canOwn = own_supported(2 * rSize) && c->capOwner >= own_owner_bytes(2 * rSize) &&
                             c->capQueue >= own_queue_bytes(rSize);

@@ -55,7 +55,8 @@ typedef enum {
     HJ_ALGO_AUTO   = 4   /* the reference's adaptive idea (README.md:6, the sampling pre-round of
                             HTMHashBuild.hpp:98-154 and its 0.4 % / 2 % thresholds :209-210): sample R for
                             locality; with locality run the no-partition path (HJ_ALGO_ATOMIC, LDS-window
-                            build), otherwise the radix join (HJ_ALGO_PRJ). hj_result.algoUsed says which;
+                            build), otherwise the radix join (HJ_ALGO_PRJ) -- also when rSize is not a power of
+                            two, which the table join does not take. hj_result.algoUsed says which;
                             totalMatches agrees between the two whenever R has unique keys */
 } hj_algo;
 

@@ -110,6 +110,11 @@ def test_algo_auto_switches_between_table_and_radix_join(ctx):
             want = oracle.prj_join(R, S, got["radixBits"])
             assert (got["totalMatches"], got["prjChecksum"]) == (want["matches"], want["checksum"])
             assert got["totalMatches"] == n
+    # a relation size the table join does not take (not a power of two): auto is the radix join
+    R = oracle.generate_data("sorted", n)[: n - 12345]
+    S = oracle.generate_data("sorted", n)
+    got = ctx.run("auto", R, S)
+    assert got["algoUsed"] == "prj" and got["totalMatches"] == R.size
     # split API: hj_reserve("auto") + hj_join_dev on device pointers, R only
     R = oracle.generate_data("shuffle", n)
     with hj.HashJoinContext(0) as c2:
