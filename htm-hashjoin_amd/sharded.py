@@ -311,6 +311,25 @@ def _local_roofline(res):
             "launch_us": loc["buildPhaseA_us"]}
 
 
+def rank_key_range(world, n, rank):
+    """(lo, width): rank `rank` of `world` draws its n keys from (lo, lo + width]. While the whole relation fits the
+    32-bit key space that is (rank*n, (rank+1)*n]; otherwise the rank-th of `world` equal cuts of the key space (the
+    last one ends at 2^32 - 1), so that the range split's digit ((key - 1) >> d) names the owner of every key."""
+    wrap = (1 << 32) - 1
+    if world * n <= wrap:
+        return rank * n, n
+    cut = (wrap + world) // world                                 # 2^32 / world for a power-of-two world
+    return rank * cut, min(cut, wrap - rank * cut)
+
+
+def squeeze_into_range(v, n, lo, width, np):
+    """values in [1, n] -> keys in (lo, lo + width], order kept (width < n: neighbouring values share a key)"""
+    v = v - np.uint64(1)
+    if width != n:
+        v = (v * np.uint64(width)) // np.uint64(n)
+    return v + np.uint64(lo + 1)
+
+
 def bench_sharded(args, torch, dist, hj, rank, world, local_rank):
     """bench.py's N > 1 leg. Default = WEAK scaling: every rank holds 2^log2n tuples of R and of S (the N=1
     workload per GPU; 8 GPUs x 2^30 = BASELINE config 4); --strong keeps the N=1 total and splits it.
@@ -324,22 +343,13 @@ def bench_sharded(args, torch, dist, hj, rank, world, local_rank):
     n = (1 << args.log2n) >> (strip if args.strong else 0)          # tuples per rank and relation
     window = args.shuffle_range
     wrap = (1 << 32) - 1
-    # rank g's key range: (g*n, (g+1)*n] while the whole relation fits the 32-bit key space; otherwise the g-th of
-    # `world` equal cuts of that space (the last one ends at 2^32 - 1)
-    if world * n <= wrap:
-        lo, width = rank * n, n
-    else:
-        cut = (wrap + world) // world                                 # 2^32 / world for a power-of-two world
-        lo, width = rank * cut, min(cut, wrap - rank * cut)
+    lo, width = rank_key_range(world, n, rank)
     R = hj.generate_data(args.dist, n, n, window)                    # values in [1, n] (uniform and the unique-key kinds)
 
-    def to_range(v):                                                 # [1, n] -> (lo, lo + width], order kept
+    def to_range(v):
         if args.dist == "random":                                    # 31-bit random keys: no range to speak of
             return v
-        v = v - np.uint64(1)
-        if width != n:
-            v = (v * np.uint64(width)) // np.uint64(n)
-        return v + np.uint64(lo + 1)
+        return squeeze_into_range(v, n, lo, width, np)
     r_local = torch.from_numpy(to_range(R).view("int64")).to(f"cuda:{local_rank}")
     # S as main.cpp:91-97 builds it: sorted 1..N on the same key range (for `random`: R itself)
     S = R.copy() if args.dist == "random" else to_range(np.arange(1, n + 1, dtype=np.uint64))
