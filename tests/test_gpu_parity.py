@@ -307,6 +307,28 @@ def test_config2_size_properties(ctx):
     assert got["totalMatches"] == n and got["prjChecksum"] == 549688705024            # motivation_log1:8
 
 
+def test_maximum_relation_size():
+    """rSize = 2^31, the largest power of two the reference's uint32_t sizes hold (table of 2^32 slots = 32 GiB, slot
+    numbers use all 32 bits): local_shuffle W=1024 against S = sorted. Unique keys: no conflicts, every probe matches,
+    the closed-form sums. ~110 GiB of HBM."""
+    n = 1 << 31
+    R = hj.generate_data("local_shuffle", n, n, 1024)
+    with hj.HashJoinContext(0) as c:
+        dR = c.dev_alloc(n * 8); c.copy_h2d(dR, R)
+        del R
+        S = hj.generate_data("sorted", n)
+        dS = c.dev_alloc(n * 8); c.copy_h2d(dS, S)
+        del S
+        c.reserve("atomic", n, n)
+        c.build(dR, n); c.probe(dS, n)
+        c.checksums()
+        r = c.fetch()
+        c.dev_free(dR); c.dev_free(dS)
+    tri = n * (n + 1) // 2
+    assert (r["conflicts"], r["totalMatches"], r["inputSum"], r["tableSumFull"], r["buildVariant"]) == (0, n, tri, tri, 2)
+    assert r["tableSumHalf"] == tri - n            # the nocc quirk: slots [0, rSize) miss key N, which sits in slot N
+
+
 # ---- radix-sharded path: every GPU kernel of htm_hashjoin_amd/sharded.py on one device ------------
 @pytest.mark.parametrize("G", [2, 8, 64])
 @pytest.mark.parametrize("dist,window", [("uniform", 16), ("local_shuffle", 1024), ("random", 16)])
