@@ -310,7 +310,7 @@ def test_config2_size_properties(ctx):
 def test_maximum_relation_size():
     """rSize = 2^31, the largest power of two the reference's uint32_t sizes hold (table of 2^32 slots = 32 GiB, slot
     numbers use all 32 bits): local_shuffle W=1024 against S = sorted. Unique keys: no conflicts, every probe matches,
-    the closed-form sums. ~110 GiB of HBM."""
+    the closed-form sums; then the radix join of the same relations. ~160 GiB of HBM."""
     n = 1 << 31
     R = hj.generate_data("local_shuffle", n, n, 1024)
     with hj.HashJoinContext(0) as c:
@@ -323,6 +323,11 @@ def test_maximum_relation_size():
         c.build(dR, n); c.probe(dS, n)
         c.checksums()
         r = c.fetch()
+        with hj.HashJoinContext(0) as c2:          # the radix join on the same device buffers (32-bit element indices)
+            c2.reserve("prj", n, n)
+            c2.prj_join(dR, n, dS, n)
+            p = c2.fetch()
+        assert p["totalMatches"] == n and p["radixBits"] == 16
         c.dev_free(dR); c.dev_free(dS)
     tri = n * (n + 1) // 2
     assert (r["conflicts"], r["totalMatches"], r["inputSum"], r["tableSumFull"], r["buildVariant"]) == (0, n, tri, tri, 2)

@@ -21,3 +21,15 @@ with hj.HashJoinContext(0) as c:
     print({k: r[k] for k in ("conflicts", "totalMatches", "inputSum", "tableSumFull", "buildVariant", "buildDeferred", "build_us", "probe_us")})
     assert r["conflicts"] == 0 and r["totalMatches"] == n and r["inputSum"] == n * (n + 1) // 2 == r["tableSumFull"]
     print("max size OK", 2 * n / (r["build_us"] + r["probe_us"]), "Mtuples/s")
+# the radix join at the same size (element indices are 32-bit: sizes up to 2^32 - 2)
+with hj.HashJoinContext(0) as c:
+    R = hj.generate_data("local_shuffle", n, n, 1024)
+    dR = c.dev_alloc(n * 8); c.copy_h2d(dR, R); del R
+    S = hj.generate_data("sorted", n)
+    dS = c.dev_alloc(n * 8); c.copy_h2d(dS, S); del S
+    c.reserve("prj", n, n)
+    c.prj_join(dR, n, dS, n)
+    r = c.fetch()
+    print({k: r[k] for k in ("totalMatches", "prjChecksum", "radixBits", "partition_us", "join_us")})
+    assert r["totalMatches"] == n
+    print("PRJ max size OK", 2 * n / r["total_us"], "Mtuples/s")
