@@ -327,7 +327,8 @@ int hj_build_dev(hj_ctx* c, const uint64_t* dR, uint64_t rSize, uint64_t idxBase
     if (c->params.algo == HJ_ALGO_PRJ) return fail(c, HJ_ERR_STATE, "hj_build_dev: context is reserved for PRJ");
     if (!is_pow2(rSize) || 2 * rSize + kTableSlack > c->tableCapSlots)
         return fail(c, HJ_ERR_STATE, "hj_build_dev: hj_reserve() not called for this rSize");
-    if (idxBase + rSize > (1ull << 32)) return fail(c, HJ_ERR_INVALID, "hj_build_dev: index range exceeds 32 bits");
+    // indices stay below 2^32 - 1: (index << 32 | key) of index = key = 0xFFFFFFFF would be the empty pattern
+    if (idxBase + rSize > 0xFFFFFFFFull) return fail(c, HJ_ERR_INVALID, "hj_build_dev: index range exceeds 2^32 - 1");
     return build_common(c, dR, false, rSize, 0, 2 * rSize, idxBase);
 }
 
@@ -338,7 +339,7 @@ int hj_build_keys_dev(hj_ctx* c, const uint32_t* dKeys, uint64_t n, uint32_t hom
     if (homeShift > 6) return fail(c, HJ_ERR_INVALID, "hj_build_keys_dev: homeShift must be in [0,6]");
     if (!is_pow2(tableSize) || tableSize + kTableSlack > c->tableCapSlots)
         return fail(c, HJ_ERR_STATE, "hj_build_keys_dev: hj_reserve() not called for this table size");
-    if (n > (1ull << 32)) return fail(c, HJ_ERR_INVALID, "hj_build_keys_dev: index range exceeds 32 bits");
+    if (n > 0xFFFFFFFFull) return fail(c, HJ_ERR_INVALID, "hj_build_keys_dev: index range exceeds 2^32 - 1");
     return build_common(c, dKeys, true, n, homeShift, tableSize, 0);
 }
 
@@ -373,6 +374,7 @@ int hj_probe_keys_dev(hj_ctx* c, const uint32_t* dKeys, uint64_t n)
 int hj_prj_join_dev(hj_ctx* c, const uint64_t* dR, uint64_t rSize, const uint64_t* dS, uint64_t sSize)
 {
     if (!c || !dR || rSize == 0) return HJ_ERR_INVALID;
+    if (sSize == 0) dS = nullptr;                    // an empty S is no S (the join kernel clamps its loads to nS - 1)
     if (c->params.algo != HJ_ALGO_PRJ && c->params.algo != HJ_ALGO_AUTO)
         return fail(c, HJ_ERR_STATE, "hj_prj_join_dev: context not reserved for PRJ");
     const uint64_t nmax = rSize > sSize ? rSize : sSize;
@@ -402,6 +404,7 @@ int hj_join_dev(hj_ctx* c, const uint64_t* dR, uint64_t rSize, const uint64_t* d
 {
     if (!c || !dR || rSize == 0) return HJ_ERR_INVALID;
     if (!dS) sSize = 0;
+    if (sSize == 0) dS = nullptr;
     int rc;
     bool prj = c->params.algo == HJ_ALGO_PRJ;
     uint32_t force = 0;
@@ -516,6 +519,16 @@ int hj_run(hj_ctx* c, const hj_params* params, const uint64_t* relR, uint64_t rS
     if ((rc = hj_join_dev(c, c->stageR, rSize, sSize ? c->stageS : nullptr, sSize))) return rc;
     if (!c->prjRan && (rc = hj_checksums_dev(c))) return rc;
     return hj_fetch_result(c, out);
+}
+
+int hj_prj_workspace_info(uint64_t rSize, uint64_t sSize, uint32_t radixBits, uint64_t out[4])
+{
+    if (!out || radixBits > 16) return HJ_ERR_INVALID;
+    const uint32_t bits = radixBits ? radixBits : auto_radix_bits(rSize);
+    const PrjPlan pl = prj_plan(rSize, sSize, bits);
+    out[0] = pl.workspaceBytes; out[1] = pl.histEntries;
+    out[2] = prj_hist_entries_needed(rSize, bits); out[3] = prj_hist_entries_needed(sSize, bits);
+    return HJ_OK;
 }
 
 // ---- shard helpers -----------------------------------------------------------

@@ -88,11 +88,17 @@ void launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshift, ui
 struct PrjPlan {
     uint32_t radixBits;   // total
     uint32_t bits1, bits2;
-    uint64_t maxChunks1, maxChunks2;   // chunk descriptors per pass (upper bounds)
+    uint64_t maxChunks1, maxChunks2;   // chunk descriptors per pass (upper bounds over both relations)
+    uint64_t histEntries, scanBlocks;  // histogram / block-sum entries: the larger need of R's and S's layouts in
+                                       // either pass (the chunk length, hence the chunk count, is NOT monotone in
+                                       // the relation size: the smaller relation can need the larger histogram)
     size_t   workspaceBytes;           // everything below, excluding tuple buffers
 };
-// Sizes the workspace for (nR, nS).
+// Sizes the workspace for (nR, nS): each relation is laid out with its own chunk length (run_pass), so every
+// region is the maximum over the two relations' layouts.
 PrjPlan prj_plan(uint64_t nR, uint64_t nS, uint32_t radixBits);
+// histogram entries the passes over ONE relation of n tuples write (what run_pass memsets and scans)
+uint64_t prj_hist_entries_needed(uint64_t n, uint32_t radixBits);
 struct PrjBuffers {
     uint64_t* tmpA;      // max(nR,nS) tuples
     uint64_t* partR;     // nR tuples (final partitioned R)

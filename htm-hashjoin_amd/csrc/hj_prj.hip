@@ -684,45 +684,57 @@ PrjPlan prj_plan(uint64_t nR, uint64_t nS, uint32_t radixBits)
     pl.radixBits = radixBits;
     if (radixBits <= 8) { pl.bits1 = radixBits; pl.bits2 = 0; }
     else { pl.bits1 = radixBits / 2; pl.bits2 = radixBits - pl.bits1; }  // prj_thread :814-816
-    const uint64_t n = nR > nS ? nR : nS;
     const uint32_t F1 = 1u << pl.bits1, F2 = 1u << pl.bits2;
-    const PassLayout l1 = pass_layout(n, 1, F1);
-    const PassLayout l2 = pass_layout(n, F1, F2);
-    pl.maxChunks1 = l1.maxChunks;
-    pl.maxChunks2 = l2.maxChunks;
-    const uint64_t histMax = l1.histEntries > l2.histEntries ? l1.histEntries : l2.histEntries;
-    const uint64_t sumsMax = l1.scanBlocks > l2.scanBlocks ? l1.scanBlocks : l2.scanBlocks;
+    // run_pass lays every relation out with pick_chunk_len of ITS size, and the chunk count is not monotone in
+    // the size (chunkLen doubles at the 8192 -> 16384 step: |R| = 40e6 has fewer chunks than |S| = 2^25), so
+    // each region takes the larger of the two relations' needs, pass by pass
+    for (const uint64_t n : {nR, nS}) {
+        if (n == 0) continue;
+        const PassLayout l1 = pass_layout(n, 1, F1);
+        const PassLayout l2 = pass_layout(n, F1, F2);
+        if (l1.maxChunks > pl.maxChunks1) pl.maxChunks1 = l1.maxChunks;
+        if (l2.maxChunks > pl.maxChunks2) pl.maxChunks2 = l2.maxChunks;
+        for (const PassLayout& l : {l1, l2}) {
+            if (l.histEntries > pl.histEntries) pl.histEntries = l.histEntries;
+            if (l.scanBlocks > pl.scanBlocks) pl.scanBlocks = l.scanBlocks;
+        }
+    }
     const uint64_t P = (uint64_t)F1 * F2;
     size_t bytes = 0;
     bytes += align_up(sizeof(uint32_t) * 2, 256);               // seg0
     bytes += align_up(sizeof(uint32_t) * (F1 + 1), 256);        // seg1 (after pass 1)
     bytes += align_up(sizeof(uint32_t) * (F1 + 2), 256);        // chunkBase
-    bytes += align_up(sizeof(uint32_t) * histMax, 256);         // hist / scanned
-    bytes += align_up(sizeof(uint32_t) * (sumsMax + 1), 256);   // block sums
+    bytes += align_up(sizeof(uint32_t) * pl.histEntries, 256);  // hist / scanned
+    bytes += align_up(sizeof(uint32_t) * (pl.scanBlocks + 1), 256);   // block sums
     bytes += 2 * align_up(sizeof(uint32_t) * (P + 1), 256);     // final offsets R, S
     pl.workspaceBytes = bytes;
     return pl;
+}
+
+uint64_t prj_hist_entries_needed(uint64_t n, uint32_t radixBits)
+{
+    const PrjPlan shape = prj_plan(0, 0, radixBits);            // bit split only
+    const uint32_t F1 = 1u << shape.bits1, F2 = 1u << shape.bits2;
+    if (n == 0) return 0;
+    const uint64_t a = pass_layout(n, 1, F1).histEntries, b = pass_layout(n, F1, F2).histEntries;
+    return a > b ? a : b;
 }
 
 namespace {
 struct Work {
     uint32_t *seg0, *seg1, *chunkBase, *hist, *sums, *offR, *offS;
 };
-Work carve(const PrjPlan& pl, void* base, uint64_t n)
+Work carve(const PrjPlan& pl, void* base)
 {
     const uint32_t F1 = 1u << pl.bits1, F2 = 1u << pl.bits2;
-    const PassLayout l1 = pass_layout(n, 1, F1);
-    const PassLayout l2 = pass_layout(n, F1, F2);
-    const uint64_t histMax = l1.histEntries > l2.histEntries ? l1.histEntries : l2.histEntries;
-    const uint64_t sumsMax = l1.scanBlocks > l2.scanBlocks ? l1.scanBlocks : l2.scanBlocks;
     const uint64_t P = (uint64_t)F1 * F2;
     char* p = static_cast<char*>(base);
     Work w;
     w.seg0 = reinterpret_cast<uint32_t*>(p); p += align_up(sizeof(uint32_t) * 2, 256);
     w.seg1 = reinterpret_cast<uint32_t*>(p); p += align_up(sizeof(uint32_t) * (F1 + 1), 256);
     w.chunkBase = reinterpret_cast<uint32_t*>(p); p += align_up(sizeof(uint32_t) * (F1 + 2), 256);
-    w.hist = reinterpret_cast<uint32_t*>(p); p += align_up(sizeof(uint32_t) * histMax, 256);
-    w.sums = reinterpret_cast<uint32_t*>(p); p += align_up(sizeof(uint32_t) * (sumsMax + 1), 256);
+    w.hist = reinterpret_cast<uint32_t*>(p); p += align_up(sizeof(uint32_t) * pl.histEntries, 256);
+    w.sums = reinterpret_cast<uint32_t*>(p); p += align_up(sizeof(uint32_t) * (pl.scanBlocks + 1), 256);
     w.offR = reinterpret_cast<uint32_t*>(p); p += align_up(sizeof(uint32_t) * (P + 1), 256);
     w.offS = reinterpret_cast<uint32_t*>(p);
     return w;
@@ -771,8 +783,7 @@ void partition_relation(const PrjPlan& pl, const Work& w, const uint64_t* in, ui
 void launch_prj(const PrjPlan& pl, const PrjBuffers& buf, const uint64_t* R, uint64_t nR,
                 const uint64_t* S, uint64_t nS, Counters* ctr, hipEvent_t evPartDone, hipStream_t s)
 {
-    const uint64_t n = nR > nS ? nR : nS;
-    const Work w = carve(pl, buf.work, n);
+    const Work w = carve(pl, buf.work);
     uint32_t* const tmp = reinterpret_cast<uint32_t*>(buf.tmpA);
     uint32_t* const partR = reinterpret_cast<uint32_t*>(buf.partR);
     uint32_t* const partS = reinterpret_cast<uint32_t*>(buf.partS);

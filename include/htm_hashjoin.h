@@ -212,6 +212,12 @@ int hj_probe_keys_dev(hj_ctx *ctx, const uint32_t *dKeys, uint64_t n);
  * rank, else redoes the step with split + exchange. nShards = 0 switches the check off. */
 int hj_set_shard_check(hj_ctx *ctx, uint32_t nShards, uint32_t mode, uint32_t shardId);
 
+/* Host-only arithmetic (no device needed): how hj_reserve sizes the PRJ histogram workspace for (rSize, sSize,
+ * radixBits; 0 = auto). out[0] = workspace bytes, out[1] = histogram entries planned, out[2] / out[3] = entries the
+ * passes over R / over S write. Each relation is chunked by its own size (mc's per-thread slices,
+ * parallel_radix_join.c:586-617, become per-chunk histograms), so out[1] >= max(out[2], out[3]) must hold. */
+int hj_prj_workspace_info(uint64_t rSize, uint64_t sSize, uint32_t radixBits, uint64_t out[4]);
+
 /* ---- device memory for hosts without a HIP runtime of their own ----------- */
 int hj_dev_alloc(hj_ctx *ctx, uint64_t bytes, void **dptr);
 int hj_dev_free(hj_ctx *ctx, void *dptr);

@@ -68,3 +68,24 @@ def test_product_does_not_reference_the_oracle():
                 assert "oracle" not in text.lower(), os.path.join(dirpath, f)
     out = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def test_prj_workspace_covers_both_relations_layouts():
+    """hj_reserve sizes the PRJ histogram region for the larger NEED of the two relations, not for the larger
+    relation: the chunk length doubles at the 8192 -> 16384 step, so |R| = 40e6 has fewer chunks than |S| = 2^25
+    (round-1 ADVICE: a 700 KB out-of-bounds device write). Host arithmetic only."""
+    out = (ctypes.c_uint64 * 4)()
+    sizes = [1, 1000, 8191, 8192, 1 << 20, (1 << 25) - 1, 1 << 25, 33_560_000, 40_000_000, 1 << 26, 100_000_000,
+             (1 << 27) + 12345, 1 << 28, 268_500_000, 1 << 30, (1 << 31) + 7, (1 << 32) - 2]
+    worst = 0.0
+    for bits in (0, 1, 8, 9, 14, 16):
+        for a in sizes:
+            for b in sizes + [0]:
+                assert hj.lib.hj_prj_workspace_info(a, b, bits, out) == 0
+                ws, planned, need_r, need_s = (int(x) for x in out)
+                assert planned >= need_r and planned >= need_s, (a, b, bits, planned, need_r, need_s)
+                assert ws >= 4 * planned
+                if b and a > b and need_s > need_r:
+                    worst = max(worst, need_s / need_r)
+    assert worst > 1.5          # the non-monotone case exists (and is what the region is now sized for)
+    assert hj.lib.hj_prj_workspace_info(40_000_000, 1 << 25, 14, out) == 0 and out[3] > out[2]

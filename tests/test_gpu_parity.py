@@ -271,6 +271,46 @@ def test_prj_ragged_skewed_and_r_only(ctx):
     assert got["totalMatches"] == 0 and got["prjChecksum"] == oracle.prj_join(R, None, 14)["checksum"]
 
 
+@pytest.mark.parametrize("nR,nS", [(40_000_000, 1 << 25), (1 << 25, 40_000_000)])
+def test_prj_unequal_sizes_across_the_chunk_length_step(nR, nS):
+    """|R| and |S| on opposite sides of the size where the partitioning chunk length doubles: the smaller relation
+    then has MORE chunks, and the histogram workspace must have been sized for it (round-1 ADVICE, high)."""
+    R = np.arange(1, nR + 1, dtype=np.uint64)
+    rng = np.random.default_rng(11)
+    rng.shuffle(R[: 1 << 22])                                  # some disorder without a full 40M-element shuffle
+    S = (rng.integers(0, nR + nR // 3, size=nS, dtype=np.uint64) + np.uint64(1))
+    want = oracle.prj_join(R, S, 14)
+    with hj.HashJoinContext(0) as c:
+        for algo in ("prj", "auto"):                           # AUTO with a non-power-of-two |R| is the radix join too
+            got = c.run(algo, R, S, radixBits=14)
+            assert got["algoUsed"] == "prj"
+            assert (got["totalMatches"], got["prjChecksum"]) == (want["matches"], want["checksum"]), algo
+
+
+def test_empty_s_with_a_pointer_and_index_limit(ctx):
+    """hj_prj_join_dev / hj_join_dev with dS non-null but sSize == 0 (hj_probe_dev allows an empty S): treated as
+    R-only instead of reading partS[0xFFFFFFFF]; and index 0xFFFFFFFF is refused, since (index << 32 | key) of
+    index = key = 0xFFFFFFFF would be the empty pattern (round-1 ADVICE, low)."""
+    n = 1 << 16
+    R = oracle.generate_data("shuffle", n)
+    want = oracle.prj_join(R, None, 14)
+    with hj.HashJoinContext(0) as c:
+        dR = c.dev_alloc(n * 8); dS = c.dev_alloc(64)
+        c.copy_h2d(dR, R)
+        for algo in ("prj", "auto"):
+            c.reserve(algo, n, 0, radixBits=14)
+            c.join(dR, n, dS, 0)
+            got = c.fetch()
+            assert got["algoUsed"] == "prj" and got["totalMatches"] == 0 and got["prjChecksum"] == want["checksum"]
+        c.reserve("atomic", n, 0)
+        c.build(dR, n, idx_base=(1 << 32) - 1 - n)             # last index used = 2^32 - 2: fine
+        assert c.fetch()["conflicts"] == 0
+        with pytest.raises(hj.HashJoinError) as e:
+            c.build(dR, n, idx_base=(1 << 32) - n)             # would use index 2^32 - 1
+        assert e.value.status == _lib.HJ_ERR_INVALID
+        c.dev_free(dR); c.dev_free(dS)
+
+
 # ---- full-size, size-independent properties -------------------------------------
 def test_config2_size_properties(ctx):
     """BASELINE configs[1] size (2^27): invariants that hold for any correct run, plus the
