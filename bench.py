@@ -231,12 +231,12 @@ def main():
     # roofline of the dominant kernel (the build): algorithmic bytes = 16 B per R tuple
     # (8 read + 8 slot write), duration = HIP-event time of that launch
     ku = main_leg["kernel_us"]
-    v2 = main_leg["buildVariant"] == 2
+    v2 = main_leg["buildVariant"] >= 2          # an LDS build (2: workgroup window, 3: wavefront rings): phase A timed alone
     # Dominant kernel = the build. Variant 2: k_build_own (phase A) timed alone by its own HIP events
     # (hj_result.buildPhaseA_us); build_us additionally covers k_clear_unowned + k_build_deferred.
     # Algorithmic bytes per launch: build = R read 8 + slot write 8 = 16 B per R tuple;
     # probe = S read 8 + home-slot read 8 = 16 B per S tuple; table clear = 16 B per R tuple (2|R| slots).
-    dom_name = "k_build_own" if v2 else "k_build_atomic_min"
+    dom_name = {3: "k_build_wave", 2: "k_build_own"}.get(main_leg["buildVariant"], "k_build_atomic_min")
     dom_us = ku["buildPhaseA_us"] if v2 else ku["build_us"]
     alg = 16.0 * n
     achieved = alg / (dom_us * 1e-6) / 1e9
@@ -250,7 +250,7 @@ def main():
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg, "launch_us": dom_us,
                 "other_kernels": {
-                    "build_group_us (k_build_own + k_clear_unowned + k_build_deferred)" if v2 else "k_fill_empty_us":
+                    "build_group_us (bounds pre-pass + LDS build kernel + edge/unowned clear + deferred phase)" if v2 else "k_fill_empty_us":
                         ku["build_us"] if v2 else ku["clear_us"],
                     "k_probe_us": ku["probe_us"], "k_probe_GBps": 16.0 * n / (ku["probe_us"] * 1e-6) / 1e9,
                     "k_sample_locality_plus_readback_us": ku["clear_us"] if v2 else None},

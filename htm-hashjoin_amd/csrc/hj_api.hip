@@ -20,6 +20,7 @@ enum Ev { EV_CLEAR0, EV_BUILD0, EV_BUILD_A, EV_BUILD1, EV_PROBE0, EV_PROBE1, EV_
 
 struct hj_ctx {
     int device = 0;
+    int nCU = 256;                // of THIS context's device (grids are sized per context, never from process statics)
     hipStream_t stream = nullptr;
     bool ownStream = false;
     hj_params params{};
@@ -35,8 +36,9 @@ struct hj_ctx {
     void* ownerBuf = nullptr; size_t capOwner = 0;
     void* queueBuf = nullptr; size_t capQueue = 0;
     unsigned long long* queueCount = nullptr;   // device
-    unsigned int* fitCount = nullptr;           // device
+    unsigned int* fitCount = nullptr;           // device, 4 words (launch_sample_locality)
     unsigned int* hFit = nullptr;               // pinned
+    void* boundsBuf = nullptr;                  // variant 3: per-chunk slot ranges (wave_bounds_bytes)
     uint32_t variantUsed = 1;
     // counters
     Counters* dCtr = nullptr;
@@ -135,9 +137,12 @@ int create_common(int device, void* stream, bool own, hj_ctx** out)
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return HJ_ERR_HIP;
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return HJ_ERR_NO_DEVICE;  // kernels are gfx950-only
     if (hipSetDevice(device) != hipSuccess) return HJ_ERR_HIP;
+    // the kernels with more than 64 KiB of dynamic LDS need the attribute on EVERY device they run on
+    if (own_set_attributes() != hipSuccess || prj_set_attributes() != hipSuccess) return HJ_ERR_HIP;
     hj_ctx* c = new (std::nothrow) hj_ctx();
     if (!c) return HJ_ERR_OOM;
     c->device = device;
+    c->nCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (own) {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return HJ_ERR_HIP; }
         c->ownStream = true;
@@ -147,8 +152,9 @@ int create_common(int device, void* stream, bool own, hj_ctx** out)
     bool ok = hipMalloc(reinterpret_cast<void**>(&c->dCtr), sizeof(Counters)) == hipSuccess &&
               hipHostMalloc(reinterpret_cast<void**>(&c->hCtr), sizeof(Counters)) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&c->queueCount), sizeof(unsigned long long)) == hipSuccess &&
-              hipMalloc(reinterpret_cast<void**>(&c->fitCount), 2 * sizeof(unsigned int)) == hipSuccess &&
-              hipHostMalloc(reinterpret_cast<void**>(&c->hFit), 2 * sizeof(unsigned int)) == hipSuccess;
+              hipMalloc(reinterpret_cast<void**>(&c->fitCount), 4 * sizeof(unsigned int)) == hipSuccess &&
+              hipHostMalloc(reinterpret_cast<void**>(&c->hFit), 4 * sizeof(unsigned int)) == hipSuccess &&
+              hipMalloc(&c->boundsBuf, wave_bounds_bytes(c->nCU)) == hipSuccess;
     for (int i = 0; ok && i < EV_COUNT; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
     if (!ok) { hj_destroy(c); return HJ_ERR_HIP; }
     hipMemset(c->dCtr, 0, sizeof(Counters));
@@ -182,7 +188,7 @@ void hj_destroy(hj_ctx* c)
     hipSetDevice(c->device);
     if (c->stream || !c->ownStream) hipStreamSynchronize(c->stream);
     void* frees[] = {c->table, c->dCtr, c->tmpA, c->partR, c->partS, c->work, c->stageR, c->stageS,
-                     c->ownerBuf, c->queueBuf, c->queueCount, c->fitCount, c->shard[0].work, c->shard[1].work,
+                     c->ownerBuf, c->queueBuf, c->queueCount, c->fitCount, c->boundsBuf, c->shard[0].work, c->shard[1].work,
                      c->shard[2].work, c->shard[3].work};
     for (void* p : frees) if (p) hipFree(p);
     if (c->hCtr) hipHostFree(c->hCtr);
@@ -249,11 +255,13 @@ int hj_reserve(hj_ctx* c, const hj_params* params, uint64_t rSize, uint64_t sSiz
     if (rSize > (1ull << 31)) return fail(c, HJ_ERR_INVALID, "hj_reserve: rSize > 2^31 per device");
     int rc = grow(c, c->table, c->tableCapSlots, 2 * rSize + kTableSlack);
     if (rc) return rc;
-    if (params->buildVariant > 2) return fail(c, HJ_ERR_INVALID, "hj_reserve: buildVariant must be 0, 1 or 2");
-    if (params->buildVariant != 1 && own_supported(2 * rSize)) {
+    if (params->buildVariant > 3) return fail(c, HJ_ERR_INVALID, "hj_reserve: buildVariant must be 0, 1, 2 or 3");
+    if (params->buildVariant != 1 && (own_supported(2 * rSize) || wave_supported(2 * rSize))) {
         // 1/8 headroom: a radix shard may receive slightly more than its nominal share (hj_build_keys_dev)
-        const size_t ob = own_owner_bytes(2 * rSize), qb = own_queue_bytes(rSize + rSize / 8);
-        if (ob > c->capOwner) {
+        const size_t ob = own_owner_bytes(2 * rSize);
+        size_t qb = own_queue_bytes(rSize + rSize / 8);
+        if (wave_queue_bytes(rSize + rSize / 8, c->nCU) > qb) qb = wave_queue_bytes(rSize + rSize / 8, c->nCU);
+        if (own_supported(2 * rSize) && ob > c->capOwner) {
             if (c->ownerBuf) { HJ_HIP(c, hipFree(c->ownerBuf)); c->ownerBuf = nullptr; c->capOwner = 0; }
             HJ_HIP(c, hipMalloc(&c->ownerBuf, ob)); c->capOwner = ob;
         }
@@ -265,16 +273,24 @@ int hj_reserve(hj_ctx* c, const hj_params* params, uint64_t rSize, uint64_t sSiz
     return HJ_OK;
 }
 
-// Locality pre-round: 256 sample tiles; the LDS-window kernel is worth taking if it would have to defer at
-// most 1/12 of the tuples (measured at 2^27, local_shuffle: W=2^11 defers 3.8 % and runs 2.1 ms against
-// 5.7 ms for the global-atomic kernel; W=2^12 defers 36 % and runs 12.9 ms against 5.8).
-static int sample_is_local(hj_ctx* c, const void* d, bool key32, uint64_t n, uint64_t tableSize, uint32_t hshift, bool* local)
+// Locality pre-round: 256 sample tiles of R. Answer = the build kernel worth taking:
+//   3  the wavefront-private rings (hj_build_wave.hip) if at most 1/128 of the sampled tuples would fall outside
+//      their ring (tight locality: the reference's default shuffle window of 16, anything up to ~100 positions);
+//   2  the workgroup window (hj_build_own.hip) if it would have to defer at most 1/12 of the tuples (measured at
+//      2^27, local_shuffle: W=2^11 defers 3.8 % and runs 2.1 ms against 5.7 ms for the global-atomic kernel;
+//      W=2^12 defers 36 % and runs 12.9 ms against 5.8);
+//   1  global atomics otherwise (no locality: hj_join_dev(AUTO) then takes the radix join instead).
+static int sample_variant(hj_ctx* c, const void* d, bool key32, uint64_t n, uint64_t tableSize, uint32_t hshift,
+                          bool canOwn, bool canWave, uint32_t* variant)
 {
     const uint32_t nSample = 256;
-    launch_sample_locality(d, key32, n, tableSize, hshift, nSample, c->fitCount, c->stream);
-    HJ_HIP(c, hipMemcpyAsync(c->hFit, c->fitCount, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+    HJ_HIP(c, launch_sample_locality(d, key32, n, tableSize, hshift, nSample, c->fitCount, c->stream));
+    HJ_HIP(c, hipMemcpyAsync(c->hFit, c->fitCount, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
     HJ_HIP(c, hipStreamSynchronize(c->stream));
-    *local = (uint64_t)c->hFit[0] * 12 <= (uint64_t)c->hFit[1];
+    const uint64_t outOwn = c->hFit[0], seen = c->hFit[1], outWave = c->hFit[2];
+    if (canWave && outWave * 128 <= seen) *variant = 3;
+    else if (canOwn && outOwn * 12 <= seen) *variant = 2;
+    else *variant = 1;
     return HJ_OK;
 }
 
@@ -289,34 +305,38 @@ static int build_common(hj_ctx* c, const void* d, bool key32, uint64_t n, uint32
     HJ_HIP(c, hipMemsetAsync(c->dCtr, 0, sizeof(Counters), c->stream));
     int rc;
     if ((rc = record(c, EV_CLEAR0))) return rc;
-    // which build kernel: 2 needs its buffers (hj_reserve) and a table of at least one window
+    // which build kernel: 2 and 3 need their buffers (hj_reserve) and a table of at least one window / ring
     uint32_t variant = c->forceVariant ? c->forceVariant : c->params.buildVariant;
-    const bool canOwn = own_supported(tableSize) && c->capOwner >= own_owner_bytes(tableSize) &&
+    const bool canOwn = n && own_supported(tableSize) && c->capOwner >= own_owner_bytes(tableSize) &&
                         c->capQueue >= own_queue_bytes(n);
+    const bool canWave = n && wave_supported(tableSize) && c->capQueue >= wave_queue_bytes(n, c->nCU);
+    if (variant == 3 && !canWave) variant = canOwn ? 2 : 1;
     if (variant == 2 && !canOwn) variant = 1;
     if (variant == 0) {
         variant = 1;
-        if (canOwn && n) {
-            bool local = false;
-            if ((rc = sample_is_local(c, d, key32, n, tableSize, hshift, &local))) return rc;
-            if (local) variant = 2;
-        }
+        if ((canOwn || canWave) && (rc = sample_variant(c, d, key32, n, tableSize, hshift, canOwn, canWave, &variant))) return rc;
     }
     c->variantUsed = variant;
     c->algoUsed = c->params.algo == HJ_ALGO_AUTO ? (uint32_t)HJ_ALGO_ATOMIC : c->params.algo;
-    if (variant == 2) {
+    if (variant == 3) {
         if ((rc = record(c, EV_BUILD0))) return rc;
-        launch_build_own(d, key32, n, hshift, c->table, tableSize, probe_len(c->params), idxBase, c->sc, c->ownerBuf,
-                         c->queueBuf, c->queueCount, c->dCtr, c->ev[EV_BUILD_A], c->stream);
+        HJ_HIP(c, launch_build_wave(d, key32, n, hshift, c->table, tableSize, probe_len(c->params), idxBase, c->sc, c->nCU,
+                                    c->boundsBuf, c->queueBuf, c->dCtr, c->ev[EV_BUILD_A], c->stream));
+        c->evSet[EV_BUILD_A] = true;
+    } else if (variant == 2) {
+        if ((rc = record(c, EV_BUILD0))) return rc;
+        HJ_HIP(c, launch_build_own(d, key32, n, hshift, c->table, tableSize, probe_len(c->params), idxBase, c->sc, c->nCU,
+                                   c->ownerBuf, c->queueBuf, c->queueCount, c->dCtr, c->ev[EV_BUILD_A], c->stream));
         c->evSet[EV_BUILD_A] = true;
     } else {
         launch_fill_empty(c->table, tableSize + kTableSlack, c->stream);
         launch_set_full_range(tableSize, c->dCtr, c->stream);
+        HJ_HIP(c, hipGetLastError());
         if ((rc = record(c, EV_BUILD0))) return rc;
         if (n) launch_build_atomic_min(d, key32, n, c->table, tableSize, hshift, probe_len(c->params), idxBase, c->sc, c->dCtr, c->stream);
     }
-    if ((rc = record(c, EV_BUILD1))) return rc;
     HJ_HIP(c, hipGetLastError());
+    if ((rc = record(c, EV_BUILD1))) return rc;
     c->built = true;
     return HJ_OK;
 }
@@ -391,7 +411,7 @@ int hj_prj_join_dev(hj_ctx* c, const uint64_t* dR, uint64_t rSize, const uint64_
     int rc;
     if ((rc = record(c, EV_PRJ0))) return rc;
     PrjBuffers buf{c->tmpA, c->partR, c->partS, c->work};
-    launch_prj(pl, buf, dR, rSize, dS, dS ? sSize : 0, c->dCtr, c->ev[EV_PRJ_PART], c->stream);
+    HJ_HIP(c, launch_prj(pl, buf, dR, rSize, dS, dS ? sSize : 0, c->nCU, c->dCtr, c->ev[EV_PRJ_PART], c->stream));
     c->evSet[EV_PRJ_PART] = true;
     if ((rc = record(c, EV_PRJ1))) return rc;
     HJ_HIP(c, hipGetLastError());
@@ -416,12 +436,14 @@ int hj_join_dev(hj_ctx* c, const uint64_t* dR, uint64_t rSize, const uint64_t* d
         if (!is_pow2(rSize) || rSize > (1ull << 31)) return hj_prj_join_dev(c, dR, rSize, dS, sSize);   // see hj_reserve
         if (2 * rSize + kTableSlack > c->tableCapSlots)
             return fail(c, HJ_ERR_STATE, "hj_join_dev: hj_reserve() not called for this rSize");
-        bool local = false;
         const bool canOwn = own_supported(2 * rSize) && c->capOwner >= own_owner_bytes(2 * rSize) &&
                             c->capQueue >= own_queue_bytes(rSize);
-        if (canOwn && c->params.buildVariant != 1 && (rc = sample_is_local(c, dR, false, rSize, 2 * rSize, 0, &local))) return rc;
-        prj = !local;
-        force = 2;
+        const bool canWave = wave_supported(2 * rSize) && c->capQueue >= wave_queue_bytes(rSize, c->nCU);
+        uint32_t v = 1;
+        if ((canOwn || canWave) && c->params.buildVariant != 1 &&
+            (rc = sample_variant(c, dR, false, rSize, 2 * rSize, 0, canOwn, canWave, &v))) return rc;
+        prj = v == 1;                 // no locality: both table phases would be random HBM accesses
+        force = v;
     }
     if (prj) return hj_prj_join_dev(c, dR, rSize, dS, sSize);
     c->forceVariant = force;
@@ -569,8 +591,7 @@ int hj_shard_histogram_dev(hj_ctx* c, const uint64_t* dIn, uint64_t n, uint32_t 
         slot->cap = need;
     }
     slot->in = dIn; slot->n = n; slot->nShards = nShards; slot->mode = mode; slot->stamp = ++c->shardStamp;
-    launch_shard_hist(dIn, n, nShards, mode, slot->work, reinterpret_cast<unsigned long long*>(dCounts), c->stream);
-    HJ_HIP(c, hipGetLastError());
+    HJ_HIP(c, launch_shard_hist(dIn, n, nShards, mode, slot->work, reinterpret_cast<unsigned long long*>(dCounts), c->stream));
     return HJ_OK;
 }
 
@@ -584,8 +605,7 @@ int hj_shard_scatter_dev(hj_ctx* c, const uint64_t* dIn, uint64_t n, uint32_t nS
     for (auto& sp : c->shard) if (sp.in == dIn && sp.n == n && sp.nShards == nShards && sp.mode == mode && sp.work) slot = &sp;
     if (!slot) return fail(c, HJ_ERR_STATE, "hj_shard_scatter_dev: call hj_shard_histogram_dev on this input (same nShards and mode) first");
     HJ_HIP(c, hipSetDevice(c->device));
-    launch_shard_scatter_ordered(dIn, n, nShards, mode, slot->work, dOutKeys, c->stream);
-    HJ_HIP(c, hipGetLastError());
+    HJ_HIP(c, launch_shard_scatter_ordered(dIn, n, nShards, mode, slot->work, dOutKeys, c->stream));
     slot->in = nullptr;   // consumed
     return HJ_OK;
 }

@@ -40,7 +40,6 @@
 
 #include "hj_device.h"
 
-#include <cstdlib>
 #include <type_traits>
 
 namespace hj {
@@ -54,8 +53,6 @@ constexpr uint32_t kBlkSlots = 1u << kBlkShift;  // 512 slots = 4 KiB
 constexpr uint32_t kWinBlocks = 16;
 constexpr uint32_t kWinSlots = kBlkSlots * kWinBlocks;   // 8192 slots = 64 KiB
 constexpr uint32_t kBackBlocks = 2;              // window keeps this much room behind a tile's lowest key
-
-struct DeferredEntry { uint64_t pos; uint64_t packed; };
 
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 {
@@ -96,7 +93,7 @@ constexpr int kQCap = 128;                        // per-wavefront retry queue e
 //               atomicMin) run on 64 queue entries at a time, so every round is dense regardless of
 //               how long individual probe/displacement chains get.
 // All per-tuple arithmetic is 32-bit: key = low word, slot numbers < 2^32, value = {key, index}.
-template <bool KEY32, int ABL = 0, bool CHECK = false>
+template <bool KEY32, bool CHECK = false>
 __global__ void __launch_bounds__(kOwnThreads, 4)
 k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
             uint64_t* __restrict__ table, uint64_t mask, uint32_t hshift, uint32_t probeLen, uint64_t idxBase, ShardCheck sc,
@@ -272,7 +269,7 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
                 haveWin = true;
             } else if (nb > wb) {
                 // retire blocks [wb, min(nb, wb+K)): owned ones go to HBM whole (empties included), then their
-                // LDS copy is reset (ablation: this phase is 200 of 550 us at 2^27). ownedMask still describes
+                // LDS copy is reset (ablation, round 1: this phase is 200 of 550 us at 2^27). ownedMask still describes
                 // the window of the previous tile, i.e. exactly the blocks that leave.
                 const uint32_t nRetire = (nb - wb) < kWinBlocks ? (nb - wb) : kWinBlocks;
                 constexpr uint32_t kVecPerBlk = kBlkSlots / 2;                      // 256 x 16 B
@@ -281,13 +278,13 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
                 // (more vectors in flight per thread spill: the kernel sits at the 128-VGPR cap)
                 (void)kRetireIter;
                 const uint32_t half = threadIdx.x / kVecPerBlk, v = threadIdx.x % kVecPerBlk;
-                for (uint32_t r0 = 0; r0 < nRetire && !(ABL & 16); r0 += kOwnThreads / kVecPerBlk) {
+                for (uint32_t r0 = 0; r0 < nRetire; r0 += kOwnThreads / kVecPerBlk) {
                     const uint32_t r = r0 + half;
                     const uint32_t blk = wb + r, ring = blk & (kWinBlocks - 1);
                     if (r < nRetire && ((ownedMask >> ring) & 1u)) {
                         ulonglong2* src = reinterpret_cast<ulonglong2*>(win + ((uint64_t)ring << kBlkShift)) + v;
                         const ulonglong2 t = *src;
-                        if (!(ABL & 4)) reinterpret_cast<ulonglong2*>(table + ((uint64_t)blk << kBlkShift))[v] = t;
+                        reinterpret_cast<ulonglong2*>(table + ((uint64_t)blk << kBlkShift))[v] = t;
                         *src = make_ulonglong2(kEmpty, kEmpty);
                     }
                 }
@@ -305,7 +302,7 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
         // across a chunk seam must not take a whole block from the neighbour chunk that fills it
         // (they are deferred instead). Elsewhere any touched block is claimed.
         const bool seamTile = firstTile || lastTile;
-        if (haveWin && !(ABL & 8)) {
+        if (haveWin) {
 #pragma unroll
             for (int j = 0; j < kPerThread; ++j) {
                 const uint32_t home = (klo[j] >> hshift) & mask32;
@@ -338,11 +335,9 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
             for (int off = 8; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(mx, off, 64); mx = o > mx ? o : mx; }
             if (t < kWinBlocks) {
                 need[t] = 0;
-                if ((ABL & 8) && owned[t] == 0) owned[t] = 1u;
-                if (!(ABL & 8) && c && (c >= 0x10000u || c * 4 >= mx) && owned[t] == 0) {
+                if (c && (c >= 0x10000u || c * 4 >= mx) && owned[t] == 0) {
                     const uint32_t blk = wb + ((t - wb) & (kWinBlocks - 1));   // ring position -> block in [wb, wb+K)
-                    if (ABL & 2) owned[t] = 1u;
-                    else owned[t] = (blk < numBlocks && atomicCAS(&owner[blk], 0u, me) == 0u) ? 1u : 2u;
+                    owned[t] = (blk < numBlocks && atomicCAS(&owner[blk], 0u, me) == 0u) ? 1u : 2u;
                     if (owned[t] == 1u) { usedLo = blk < usedLo ? blk : usedLo; usedHi1 = blk + 1 > usedHi1 ? blk + 1 : usedHi1; }
                 }
             }
@@ -354,7 +349,6 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
         // ---- insert: fast step per 64 consecutive tuples, everything else through the retry queue ----
 #pragma unroll
         for (int j = 0; j < kPerThread; ++j) {
-            if (ABL & 1) break;
             while (qCount >= kDrainAt) retry_round();                   // keep room for one full step
             const bool lv = (liveMask >> j) & 1u;
             uint32_t mlo = klo[j];
@@ -511,8 +505,9 @@ k_build_deferred(const DeferredEntry* __restrict__ queue, const unsigned long lo
 // Locality probe (the reference samples a prefix to decide whether to switch to the
 // radix join, HTMHashBuild.hpp:100-154): over nSample tiles spread across R, count the
 // tuples that would fall outside the LDS window k_build_own would place for their tile
-// (window base = the tile's lowest home block - kBackBlocks) and therefore be deferred.
-// out[0] = tuples outside, out[1] = tuples looked at.
+// (window base = the tile's lowest home block - kBackBlocks) and therefore be deferred, and the
+// same for the 8 KiB ring k_build_wave would place for each of the tile's eight wavefront tiles.
+// out[0] = tuples outside variant 2's window, out[1] = tuples looked at, out[2] = outside variant 3's ring.
 template <bool KEY32>
 __global__ void __launch_bounds__(kBlock)
 k_sample_locality(const void* __restrict__ Rv, uint64_t n, uint64_t mask, uint32_t hshift, uint32_t nSample,
@@ -520,12 +515,13 @@ k_sample_locality(const void* __restrict__ Rv, uint64_t n, uint64_t mask, uint32
 {
     using Elem = typename std::conditional<KEY32, uint32_t, uint64_t>::type;
     const Elem* __restrict__ R = static_cast<const Elem*>(Rv);
-    __shared__ unsigned int sMinBlk, sOutside;
+    __shared__ unsigned int sMinBlk, sOutside, sOutsideWave;
     const uint64_t tiles = (n + kOwnTile - 1) / kOwnTile;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t s = blockIdx.x; s < nSample; s += gridDim.x) {
         const uint64_t tile = (tiles * s) / nSample;
         const uint64_t b = tile * kOwnTile, e = (b + kOwnTile < n) ? b + kOwnTile : n;
-        if (threadIdx.x == 0) { sMinBlk = 0xFFFFFFFFu; sOutside = 0; }
+        if (threadIdx.x == 0) { sMinBlk = 0xFFFFFFFFu; sOutside = 0; sOutsideWave = 0; }
         __syncthreads();
         uint32_t lo = 0xFFFFFFFFu;
         for (uint64_t i = b + threadIdx.x; i < e; i += kBlock) {
@@ -533,7 +529,7 @@ k_sample_locality(const void* __restrict__ Rv, uint64_t n, uint64_t mask, uint32
             lo = hb < lo ? hb : lo;
         }
         lo = wave_min_u32(lo);
-        if ((threadIdx.x & 63) == 0 && lo != 0xFFFFFFFFu) atomicMin(&sMinBlk, lo);
+        if (lane == 0 && lo != 0xFFFFFFFFu) atomicMin(&sMinBlk, lo);
         __syncthreads();
         const uint32_t wbase = sMinBlk > kBackBlocks ? sMinBlk - kBackBlocks : 0;
         uint32_t outside = 0;
@@ -541,11 +537,35 @@ k_sample_locality(const void* __restrict__ Rv, uint64_t n, uint64_t mask, uint32
             const uint32_t hb = (uint32_t)(home_slot((uint32_t)R[i], hshift, mask) >> kBlkShift);
             outside += (hb - wbase >= kWinBlocks) ? 1u : 0u;
         }
+        // variant 3: wavefront tiles of kWvTileTuples consecutive tuples; the ring of kWvRingGran granules ends just
+        // above the tile's highest home granule but never starts above its lowest (k_build_wave's rule); each of this
+        // block's wavefronts takes every fourth tile
+        uint32_t outsideWave = 0;
+        for (uint64_t sb = b + (uint64_t)wave * kWvTileTuples; sb < e; sb += (uint64_t)(kBlock / 64) * kWvTileTuples) {
+            const uint64_t se = sb + kWvTileTuples < e ? sb + kWvTileTuples : e;
+            uint32_t glo = 0xFFFFFFFFu, ghiInv = 0xFFFFFFFFu;
+            for (uint64_t i = sb + lane; i < se; i += 64) {
+                const uint32_t g = (uint32_t)(home_slot((uint32_t)R[i], hshift, mask) >> kWvGranShift);
+                glo = g < glo ? g : glo; ghiInv = ~g < ghiInv ? ~g : ghiInv;
+            }
+            glo = wave_min_u32(glo);
+            const uint32_t top = ~wave_min_u32(ghiInv) + 1;
+            uint32_t gbase = top > kWvRingGran ? top - kWvRingGran : 0;
+            gbase = gbase < glo ? gbase : glo;
+            for (uint64_t i = sb + lane; i < se; i += 64) {
+                const uint32_t g = (uint32_t)(home_slot((uint32_t)R[i], hshift, mask) >> kWvGranShift);
+                outsideWave += (g - gbase >= kWvRingGran) ? 1u : 0u;
+            }
+        }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) outside += __shfl_down(outside, off, 64);
-        if ((threadIdx.x & 63) == 0 && outside) atomicAdd(&sOutside, outside);
+        for (int off = 32; off > 0; off >>= 1) {
+            outside += __shfl_down(outside, off, 64);
+            outsideWave += __shfl_down(outsideWave, off, 64);
+        }
+        if (lane == 0 && outside) atomicAdd(&sOutside, outside);
+        if (lane == 0 && outsideWave) atomicAdd(&sOutsideWave, outsideWave);
         __syncthreads();
-        if (threadIdx.x == 0) { atomicAdd(&out[0], sOutside); atomicAdd(&out[1], (unsigned int)(e - b)); }
+        if (threadIdx.x == 0) { atomicAdd(&out[0], sOutside); atomicAdd(&out[1], (unsigned int)(e - b)); atomicAdd(&out[2], sOutsideWave); }
         __syncthreads();
     }
 }
@@ -555,94 +575,66 @@ size_t own_queue_bytes(uint64_t rSize) { return (rSize + 64) * sizeof(DeferredEn
 size_t own_owner_bytes(uint64_t tableSize) { return ((tableSize >> kBlkShift) + 1) * sizeof(unsigned int); }
 bool own_supported(uint64_t tableSize) { return tableSize >= (uint64_t)kWinSlots; }
 
-void launch_sample_locality(const void* R, bool key32, uint64_t n, uint64_t tableSize, uint32_t hshift, uint32_t nSample,
-                            unsigned int* fitCount, hipStream_t s)
+hipError_t launch_sample_locality(const void* R, bool key32, uint64_t n, uint64_t tableSize, uint32_t hshift, uint32_t nSample,
+                                  unsigned int* fitCount, hipStream_t s)
 {
-    (void)hipMemsetAsync(fitCount, 0, 2 * sizeof(unsigned int), s);
+    const hipError_t e = hipMemsetAsync(fitCount, 0, 4 * sizeof(unsigned int), s);
+    if (e != hipSuccess) return e;
     if (key32)
         hipLaunchKernelGGL(k_sample_locality<true>, dim3(nSample < 256 ? nSample : 256), dim3(kBlock), 0, s,
                            R, n, tableSize - 1, hshift, nSample, fitCount);
     else
         hipLaunchKernelGGL(k_sample_locality<false>, dim3(nSample < 256 ? nSample : 256), dim3(kBlock), 0, s,
                            R, n, tableSize - 1, hshift, nSample, fitCount);
+    return hipGetLastError();
 }
 
-void launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshift, uint64_t* table,
-                      uint64_t tableSize, uint32_t probeLen, uint64_t idxBase, ShardCheck sc, void* ownerBuf, void* queueBuf,
-                      unsigned long long* queueCount, Counters* ctr, hipEvent_t evPhaseA, hipStream_t s)
+hipError_t own_set_attributes()
 {
-    static bool attrSet = false;
-    if (!attrSet) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t));
-        attrSet = true;
+    // hipFuncAttributeMaxDynamicSharedMemorySize is per device: hj_create calls this with its device current
+    const void* ks[] = {reinterpret_cast<const void*>(k_build_own<false, false>), reinterpret_cast<const void*>(k_build_own<true, false>),
+                        reinterpret_cast<const void*>(k_build_own<false, true>), reinterpret_cast<const void*>(k_build_own<true, true>)};
+    for (const void* k : ks) {
+        const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t));
+        if (e != hipSuccess) return e;
     }
+    return hipSuccess;
+}
+
+hipError_t launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshift, uint64_t* table,
+                            uint64_t tableSize, uint32_t probeLen, uint64_t idxBase, ShardCheck sc, int nCU, void* ownerBuf,
+                            void* queueBuf, unsigned long long* queueCount, Counters* ctr, hipEvent_t evPhaseA, hipStream_t s)
+{
     const uint32_t numBlocks = (uint32_t)(tableSize >> kBlkShift);
-    (void)hipMemsetAsync(ownerBuf, 0, own_owner_bytes(tableSize), s);
-    (void)hipMemsetAsync(queueCount, 0, sizeof(unsigned long long), s);
+    hipError_t e;
+    if ((e = hipMemsetAsync(ownerBuf, 0, own_owner_bytes(tableSize), s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(queueCount, 0, sizeof(unsigned long long), s)) != hipSuccess) return e;
     // one chunk per resident workgroup (2 per CU: 76 KiB LDS each): a single wave of workgroups, no tail,
     // and the fewest chunk seams (measured: 512 chunks beat 768/1024/2048/4096 on MI355X)
-    static int nChunks = -1;
-    if (nChunks < 0) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        const char* e = getenv("HJ_OWN_CHUNKS");
-        nChunks = e ? atoi(e) : 2 * cus;
-        if (nChunks < 1) nChunks = 512;
-    }
+    const int nChunks = 2 * (nCU > 0 ? nCU : 256);
     uint64_t chunkLen = (n + nChunks - 1) / nChunks;
     chunkLen = (chunkLen + kOwnTile - 1) / kOwnTile * kOwnTile;
     if (chunkLen < (uint64_t)kOwnTile * 4) chunkLen = (uint64_t)kOwnTile * 4;
     const unsigned grid = (unsigned)((n + chunkLen - 1) / chunkLen);
-    if (sc.mask) {      // shard check requested: the instances that count foreign tuples
-        static bool attrSetC = false;
-        if (!attrSetC) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 0, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t));
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<true, 0, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t));
-            attrSetC = true;
-        }
-        if (key32)
-            hipLaunchKernelGGL((k_build_own<true, 0, true>), dim3(grid), dim3(kOwnThreads), kWinSlots * sizeof(uint64_t), s,
-                               R, n, chunkLen, table, tableSize - 1, hshift, probeLen, idxBase, sc,
-                               static_cast<unsigned int*>(ownerBuf), static_cast<DeferredEntry*>(queueBuf), queueCount, ctr);
-        else
-            hipLaunchKernelGGL((k_build_own<false, 0, true>), dim3(grid), dim3(kOwnThreads), kWinSlots * sizeof(uint64_t), s,
-                               R, n, chunkLen, table, tableSize - 1, hshift, probeLen, idxBase, sc,
-                               static_cast<unsigned int*>(ownerBuf), static_cast<DeferredEntry*>(queueBuf), queueCount, ctr);
-    } else
-    if (key32)
-        hipLaunchKernelGGL(k_build_own<true>, dim3(grid), dim3(kOwnThreads), kWinSlots * sizeof(uint64_t), s,
-                           R, n, chunkLen, table, tableSize - 1, hshift, probeLen, idxBase, sc,
-                           static_cast<unsigned int*>(ownerBuf), static_cast<DeferredEntry*>(queueBuf), queueCount, ctr);
-    else {
-        // timing-only ablations (results wrong by construction), selected by HJ_OWN_ABLATE
-        static int abl = -1;
-        if (abl < 0) { const char* e = getenv("HJ_OWN_ABLATE"); abl = e ? atoi(e) : 0; }
-#define HJ_OWN_LAUNCH(A)                                                                                          \
-        hipLaunchKernelGGL((k_build_own<false, A>), dim3(grid), dim3(kOwnThreads), kWinSlots * sizeof(uint64_t), s, \
-                           R, n, chunkLen, table, tableSize - 1, hshift, probeLen, idxBase, sc,                            \
-                           static_cast<unsigned int*>(ownerBuf), static_cast<DeferredEntry*>(queueBuf), queueCount, ctr)
-        switch (abl) {
-            case 1: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(1); break;
-            case 2: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(2); break;
-            case 3: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(3); break;
-            case 5: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(5); break;
-            case 9: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(9); break;
-            case 17: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 17>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(17); break;
-            case 25: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 25>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(25); break;
-            case 7: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_own<false, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t)); HJ_OWN_LAUNCH(7); break;
-            default: HJ_OWN_LAUNCH(0); break;
-        }
+#define HJ_OWN_LAUNCH(K32, CHK)                                                                                      \
+    hipLaunchKernelGGL((k_build_own<K32, CHK>), dim3(grid), dim3(kOwnThreads), kWinSlots * sizeof(uint64_t), s,       \
+                       R, n, chunkLen, table, tableSize - 1, hshift, probeLen, idxBase, sc,                            \
+                       static_cast<unsigned int*>(ownerBuf), static_cast<DeferredEntry*>(queueBuf), queueCount, ctr)
+    if (sc.mask) { if (key32) HJ_OWN_LAUNCH(true, true); else HJ_OWN_LAUNCH(false, true); }   // the instances that count foreign tuples
+    else { if (key32) HJ_OWN_LAUNCH(true, false); else HJ_OWN_LAUNCH(false, false); }
 #undef HJ_OWN_LAUNCH
-    }
-    if (evPhaseA) (void)hipEventRecord(evPhaseA, s);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (evPhaseA && (e = hipEventRecord(evPhaseA, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_finalize_range, dim3(1), dim3(64), 0, s, ctr, numBlocks, tableSize);
     hipLaunchKernelGGL(k_clear_unowned, dim3(2048), dim3(kBlock), 0, s, table,
                        static_cast<const unsigned int*>(ownerBuf), ctr, numBlocks, tableSize);
+    launch_build_deferred(queueBuf, queueCount, table, tableSize, hshift, probeLen, ctr, s);
+    return hipGetLastError();
+}
+
+void launch_build_deferred(const void* queueBuf, const unsigned long long* queueCount, uint64_t* table, uint64_t tableSize,
+                           uint32_t hshift, uint32_t probeLen, Counters* ctr, hipStream_t s)
+{
     hipLaunchKernelGGL(k_build_deferred, dim3(1024), dim3(kBlock), 0, s,
                        static_cast<const DeferredEntry*>(queueBuf), queueCount, table, tableSize - 1, hshift, probeLen, ctr);
 }

@@ -1,0 +1,611 @@
+// hj_build_wave.hip -- build variant 3: wavefront-private LDS windows over statically owned slot ranges.
+//
+// What it replaces: HOT LOOP 1 of the reference (NoCCHashBuild.hpp:37-62 / AtomicHashBuild.hpp:37-67, and the
+// TSX group insert of HTMHashBuild.hpp:157-238) for inputs whose locality is TIGHT -- the reference's own
+// default, `--shuffleRange 16`, and anything up to a few hundred positions of disorder. Variant 2
+// (hj_build_own.hip) keeps a 64 KiB window per 512-thread workgroup, claims table blocks with global atomics and
+// synchronises its eight wavefronts five times per tile; rocprof showed it neither HBM nor issue bound but
+// waiting (51 % of the wave-cycles parked at barriers and on dependent LDS round trips, profiles/r01_*). Here
+// nothing is shared between wavefronts, so nothing has to be waited for:
+//
+//   * R is cut into one contiguous chunk per resident wavefront (16 per CU). The chunk's slot range
+//     [bounds[c], bounds[c+1]) is fixed BEFORE the build by a pre-pass that looks at the first 64 tuples of
+//     every chunk (k_wave_bounds): start = lowest home slot among them, made monotone by a prefix maximum.
+//     A wavefront owns its range outright -- no claims, no owner table, no atomics on HBM.
+//   * The wavefront walks its chunk in tiles of 64 x PER tuples with a ring of 2^WINLOG slots (8 KiB) of ITS
+//     range in LDS. Inserts run the index-priority protocol of hj_kernels.hip with LDS atomics: the PER
+//     home-slot attempts of a tile are issued back to back (independent round trips), whatever fails goes
+//     through a compacted per-wavefront retry queue in dense rounds (as in variant 2).
+//   * When the tile's lowest home slot moves on, the ring's tail leaves for HBM in 1 KiB granules (one
+//     16-byte store per lane), empties included: every slot of the range is written exactly once, in order,
+//     by its owner. At the end of the chunk the rest of the range is written the same way.
+//   * A tuple that cannot be handled inside the range and the ring -- a straggler across a chunk seam, a key
+//     far from its neighbours, a probe walk that leaves the range -- is "aborted" into the global deferred
+//     queue with the slot it reached, and k_build_deferred (hj_build_own.hip) finishes it with global atomics
+//     after this kernel: the protocol is confluent, so WHICH tuples take that road never changes the table.
+//     On inputs without locality nearly every tuple takes it (correct, slow); hj_api.hip only picks this
+//     variant when a sample of R says the ring will do.
+//
+// All integer work on 8-byte tuples (or bare 32-bit keys); HBM traffic = R read once + every reachable slot
+// written once = the algorithmic 16 bytes per tuple of SURVEY.md 8d. No MFMA.
+
+#include "hj_device.h"
+
+#include <type_traits>
+
+namespace hj {
+
+constexpr int kWvThreads = 256;                     // 4 wavefronts per workgroup; they never synchronise
+constexpr int kWvWaves = kWvThreads / 64;
+constexpr uint32_t kGranShift = kWvGranShift;       // retire granule: 128 slots = 1 KiB = 64 lanes x 16 bytes
+constexpr uint32_t kGranSlots = 1u << kGranShift;
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+#ifndef HJ_WV_PER
+#define HJ_WV_PER 8
+#endif
+#ifndef HJ_WV_WINLOG
+#define HJ_WV_WINLOG 10
+#endif
+#ifndef HJ_WV_QCAP
+#define HJ_WV_QCAP 128
+#endif
+#ifndef HJ_WV_PF
+#define HJ_WV_PF 1
+#endif
+#ifndef HJ_WV_ABL
+#define HJ_WV_ABL 0                                 // development only (tools/mk_variant.sh): timing ablations, results wrong
+#endif
+#ifndef HJ_WV_CARRY
+#define HJ_WV_CARRY 1                               // 1: leave < 64 retry entries queued across tiles
+#endif
+constexpr int kWvPer = HJ_WV_PER;                   // tuples per lane per tile
+constexpr int kWvTile = 64 * kWvPer;
+constexpr int kWvPf = HJ_WV_PF;                     // tiles of R in flight per wavefront (register prefetch depth)
+constexpr uint32_t kWvWinLog = HJ_WV_WINLOG;
+constexpr uint32_t kWvWin = 1u << kWvWinLog;        // ring slots per wavefront
+constexpr uint32_t kWvGran = kWvWin >> kGranShift;  // ring granules
+constexpr uint32_t kWvQCap = HJ_WV_QCAP;            // retry queue entries per wavefront
+#ifndef HJ_WV_ROUNDAT
+#define HJ_WV_ROUNDAT 64
+#endif
+constexpr uint32_t kWvRoundAt = HJ_WV_ROUNDAT;      // a retry round runs once this many entries wait (<= 64)
+#ifndef HJ_WV_EXPERIMENT
+static_assert(kWvGran == kWvRingGran && kWvTile == (int)kWvTileTuples, "hj_device.h describes this geometry to the sampler");
+#endif
+static_assert(kWvQCap >= 128 && (kWvQCap & (kWvQCap - 1)) == 0, "FIFO ring: a power of two that takes one full step on top of < 64 waiting entries");
+constexpr size_t kWvLdsBytes = (size_t)kWvWaves * (kWvWin * sizeof(uint64_t) + 3 * kWvQCap * sizeof(uint32_t));
+
+__device__ __forceinline__ uint64_t wv_pack(uint32_t hi, uint32_t lo) { return ((uint64_t)hi << 32) | lo; }
+
+// minimum over the wavefront, result wave-uniform: four DPP steps inside each row of 16, then the four rows
+__device__ __forceinline__ uint32_t wave_umin(uint32_t v)
+{
+    auto step = [](uint32_t x, const int ctrl) {
+        uint32_t o;
+        switch (ctrl) {     // the control word must be an immediate
+            case 0: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xF, 0xF, true); break;   // quad_perm [1,0,3,2]
+            case 1: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xF, 0xF, true); break;   // quad_perm [2,3,0,1]
+            case 2: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xF, 0xF, true); break;  // row_half_mirror
+            default: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xF, 0xF, true); break; // row_mirror
+        }
+        return o < x ? o : x;
+    };
+    v = step(v, 0); v = step(v, 1); v = step(v, 2); v = step(v, 3);
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+
+// ---- pre-pass: where every chunk starts and which slot range it owns -----------------------------------------------
+// Chunk c nominally starts at position p = c * chunkLen. The seam is moved to where the data crosses a granule
+// boundary: with m = the lowest home slot among the 64 tuples from p, the chunk starts at the first position q in
+// [p, p + kWvLook) whose home slot lies in a later granule than m's, and its slot range starts at that granule --
+// so (on near-sorted input) no tuple before q belongs above the boundary, and the few tuples after q that still
+// belong below it are taken by the previous wavefront, which reads kWvOverlap positions past its own end. Without
+// this every seam cost ~70 deferred tuples on `uniform` (half a granule's worth), each a cascade of global atomics.
+// starts[c] = q (or p if no crossing shows up: many tuples per granule), raw[c] = the granule (kNone: no valid tuple).
+constexpr uint32_t kWvLook = 512;
+#ifndef HJ_WV_OVERLAP
+#define HJ_WV_OVERLAP 64
+#endif
+constexpr uint32_t kWvOverlap = HJ_WV_OVERLAP;
+template <bool KEY32>
+__global__ void __launch_bounds__(kBlock)
+k_wave_seams(const void* __restrict__ Rv, uint64_t n, uint32_t chunkLen, uint32_t nChunks, uint64_t mask,
+             uint32_t hshift, uint32_t* __restrict__ starts, uint32_t* __restrict__ raw)
+{
+    using Elem = typename std::conditional<KEY32, uint32_t, uint64_t>::type;
+    const Elem* __restrict__ R = static_cast<const Elem*>(Rv);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (c > nChunks) return;
+    if (c == nChunks) { if (lane == 0) starts[c] = (uint32_t)n; return; }
+    const uint64_t p = (uint64_t)c * chunkLen;
+    uint32_t h[kWvLook / 64];
+#pragma unroll
+    for (uint32_t k = 0; k < kWvLook / 64; ++k) {
+        const uint64_t i = p + 64 * k + lane;
+        h[k] = kNone;
+        if (i < n) {
+            const uint64_t t = R[i];
+            if ((t >> 32) == 0 && t != 0) h[k] = (uint32_t)home_slot((uint32_t)t, hshift, mask);
+        }
+    }
+    const uint32_t m = wave_umin(h[0]);
+    uint32_t start = (uint32_t)p, g = m == kNone ? kNone : m >> kGranShift;
+    if (c > 0 && m != kNone) {
+        const uint32_t edge = ((m >> kGranShift) + 1) << kGranShift;          // first slot of the next granule (0 on wrap: no crossing)
+        bool found = false;
+#pragma unroll
+        for (uint32_t k = 0; k < kWvLook / 64; ++k) {
+            const unsigned long long hit = __ballot(h[k] != kNone && h[k] >= edge && edge != 0);
+            if (!found && hit) {
+                found = true;
+                start = (uint32_t)(p + 64 * k + (uint32_t)__ffsll((long long)hit) - 1);
+                g = edge >> kGranShift;
+            }
+        }
+    }
+    if (lane == 0) { starts[c] = start; raw[c] = g; }
+}
+
+// bounds[c] = max over chunks <= c of raw (chunks without a valid sample inherit), bounds[nChunks] = the table's
+// end. One wavefront: 64 chunks per step, prefix maximum by shuffles.
+__global__ void __launch_bounds__(64)
+k_wave_bounds_scan(const uint32_t* __restrict__ raw, uint32_t nChunks, uint32_t numGran, uint32_t* __restrict__ bounds)
+{
+    const uint32_t lane = threadIdx.x;
+    // the first valid sample opens the first range (nothing below it is owned)
+    uint32_t first = kNone;
+    for (uint32_t b = 0; b < nChunks && first == kNone; b += 64) {
+        const uint32_t v = b + lane < nChunks ? raw[b + lane] : kNone;
+        const unsigned long long m = __ballot(v != kNone);
+        if (m) first = (uint32_t)__shfl((int)v, __ffsll((long long)m) - 1, 64);
+    }
+    uint32_t run = first == kNone ? 0u : first;
+    for (uint32_t b = 0; b < nChunks; b += 64) {
+        uint32_t v = b + lane < nChunks ? raw[b + lane] : kNone;
+        v = v == kNone ? 0u : v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)v, off, 64);
+            if ((int)lane >= off) v = o > v ? o : v;
+        }
+        v = v > run ? v : run;
+        v = v < numGran ? v : numGran;
+        if (b + lane < nChunks) bounds[b + lane] = v;
+        run = (uint32_t)__shfl((int)v, 63, 64);
+    }
+    if (lane == 0) bounds[nChunks] = numGran;
+}
+
+// ---- the build ------------------------------------------------------------------------------------------------
+template <bool KEY32, bool CHECK>
+__global__ void __launch_bounds__(kWvThreads, 4)
+k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_t nChunks, const uint32_t* __restrict__ starts,
+             const uint32_t* __restrict__ bounds, uint64_t* __restrict__ table, uint64_t mask, uint32_t hshift,
+             uint32_t probeLen, uint64_t idxBase, ShardCheck sc, DeferredEntry* __restrict__ queue,
+             uint32_t* __restrict__ dcounts, Counters* __restrict__ ctr)
+{
+    extern __shared__ __align__(16) uint64_t lds[];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t c = blockIdx.x * kWvWaves + wave;
+    if (c >= nChunks) return;                                            // whole wavefronts leave; nobody waits for them
+    uint64_t* const win = lds + wave * kWvWin;                           // ring: slot s lives at win[s & (kWvWin - 1)]
+    uint32_t* const myQPos = reinterpret_cast<uint32_t*>(lds + kWvWaves * kWvWin) + wave * 3 * kWvQCap;
+    uint32_t* const myQLo = myQPos + kWvQCap;
+    uint32_t* const myQHi = myQLo + kWvQCap;
+
+    const uint64_t cb = starts[c];
+    const uint32_t clen = starts[c + 1] - starts[c];                     // the chunk proper: its tuples are counted here
+    // ... and kWvOverlap positions of the next chunk are read too: its stragglers below the seam are inserted here
+    const uint32_t plen = (uint32_t)((cb + clen + kWvOverlap < n ? cb + clen + kWvOverlap : n) - cb);
+    const uint32_t mask32 = (uint32_t)mask;
+    const uint32_t numGran = (uint32_t)((mask + 1) >> kGranShift);
+    using Elem = typename std::conditional<KEY32, uint32_t, uint64_t>::type;
+    const Elem* __restrict__ Rc = static_cast<const Elem*>(Rv) + cb;
+    const uint32_t idx0 = (uint32_t)(idxBase + cb);
+    const bool lastChunk = c + 1 == nChunks;
+    // this wavefront's slot range, in granules: [loG, limG). The last chunk's range is open up to the table's end;
+    // how far it got is published below (ownHiEx).
+    const uint32_t loG = bounds[c];
+    const uint32_t limG = lastChunk ? numGran : bounds[c + 1];
+    const uint32_t loSlot = c ? loG << kGranShift : 0u;                 // head zone: tuples below it are the previous wavefront's
+    const uint32_t limSlot = limG << kGranShift;                        // overlap zone: only tuples below it are mine (0 = 2^32: table end)
+
+    for (uint32_t i = lane; i < kWvWin / 2; i += 64) reinterpret_cast<ulonglong2*>(win)[i] = make_ulonglong2(kEmpty, kEmpty);
+
+    uint32_t winLoG = loG;                       // ring = granules [winLoG, winLoG + kWvGran), wave-uniform
+    uint32_t qCount = 0, qHead = 0;              // retry queue (FIFO ring): entries and position of the oldest, wave-uniform
+    uint32_t rounds = 0;                         // retry rounds so far (wave-uniform)
+    unsigned long long dropSum = 0, inSum = 0;
+    uint32_t drops = 0, bad = 0, foreign = 0;
+    uint32_t dCount = 0;                         // tuples deferred so far (wave-uniform)
+    DeferredEntry* const myDeferred = queue + (uint64_t)c * sliceLen;      // <= clen + kWvOverlap <= sliceLen entries
+    uint32_t usedLo = kNone, usedHi1 = 0;        // 512-slot blocks this lane deferred into (Counters::usedLoInv / usedHi1)
+
+    // the ring's tail up to granule `target` leaves for HBM (empties included) and its LDS copy is reset
+    auto advance = [&](uint32_t target) {
+        while (winLoG < target) {
+            ulonglong2* src = reinterpret_cast<ulonglong2*>(win + ((winLoG & (kWvGran - 1)) << kGranShift)) + lane;
+            const ulonglong2 t = *src;
+            if (!(HJ_WV_ABL & 2)) reinterpret_cast<ulonglong2*>(table + ((uint64_t)winLoG << kGranShift))[lane] = t;
+            *src = make_ulonglong2(kEmpty, kEmpty);
+            ++winLoG;
+        }
+    };
+    // may this wavefront touch slot pos right now: inside the ring and inside the owned range
+    auto in_ring = [&](uint32_t pos) -> bool {
+        const uint32_t g = pos >> kGranShift;
+        return (g - winLoG < kWvGran) & (g < limG);
+    };
+
+    // One round on the entry (pos, mlo, mhi) a lane holds (hj_build_own.hip's round, with range + ring standing in
+    // for block ownership): terminal events are placed / dropped (budget exhausted, NoCCHashBuild.hpp:57-58) /
+    // deferred; returns "not finished" with the entry's next state in place.
+    auto round_body = [&](uint32_t& pos, uint32_t& mlo, uint32_t& mhi, const bool has) -> bool {
+        const uint32_t key = mlo;
+        uint32_t budget = probeLen - ((pos - ((key >> hshift) & mask32)) & mask32);
+        const bool ownOk = in_ring(pos);
+        const bool drop0 = has & (budget == 0);
+        const bool toDefer = has & !drop0 & !ownOk;
+        const bool work = has & !drop0 & ownOk;
+        const uint64_t mine = wv_pack(mhi, mlo);
+        // look before leaping: the next 4 slots, when they sit in the same granule (contiguous in the ring and owned
+        // together); slot values only decrease, so a slot seen below `mine` stays below it
+        const bool inGran = (pos & (kGranSlots - 1)) <= kGranSlots - 4;
+        const uint32_t rd = (work & inGran) ? pos : (winLoG << kGranShift);
+        const uint64_t* w = &win[rd & (kWvWin - 1)];
+        const uint64_t v0 = w[0], v1 = w[1], v2 = w[2], v3 = w[3];
+        const bool c0 = v0 < mine, c1 = c0 & (v1 < mine), c2 = c1 & (v2 < mine), c3 = c2 & (v3 < mine);
+        uint32_t skip = (uint32_t)c0 + (uint32_t)c1 + (uint32_t)c2 + (uint32_t)c3;
+        skip = (work & inGran) ? (skip < budget ? skip : budget) : 0u;
+        pos = (pos + skip) & mask32; budget -= skip;
+        const bool drop1 = work & (budget == 0);
+        const bool recheck = work & !drop1 & (skip == 4);                  // may have left the granule: next round
+        const bool doAtomic = work & !drop1 & !recheck;
+        unsigned long long old = kEmpty;
+        if (doAtomic)
+            old = atomicMin(reinterpret_cast<unsigned long long*>(&win[pos & (kWvWin - 1)]), (unsigned long long)mine);
+        const bool fail = doAtomic & (old != kEmpty) & (old != mine);
+        const bool disp = fail & (old > mine);                             // displaced a later tuple: carry it on
+        mlo = disp ? (uint32_t)old : mlo; mhi = disp ? (uint32_t)(old >> 32) : mhi;
+        const bool dropped = drop0 | drop1;
+        drops += dropped ? 1u : 0u; dropSum += dropped ? (unsigned long long)key : 0ull;
+        // deferred tuples go to this wavefront's OWN slice of the deferred queue, [cb, cb + clen): a tuple leaves at
+        // most once, so the slice cannot overflow, and no atomic is needed to place it (a returning global atomic
+        // per round with a straggler stalled the wavefront for microseconds)
+        const unsigned long long dm = __ballot(toDefer);
+        if (dm) {
+            if (toDefer) {
+                DeferredEntry* q = myDeferred + dCount + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull));
+                q->pos = pos; q->packed = mine;
+                const uint32_t db = pos >> 9;
+                usedLo = db < usedLo ? db : usedLo; usedHi1 = db + 1 > usedHi1 ? db + 1 : usedHi1;
+            }
+            dCount += (uint32_t)__popcll(dm);
+        }
+        pos = fail ? ((pos + 1) & mask32) : pos;
+        return recheck | fail;
+    };
+    // The retry queue is a FIFO ring (oldest entries first): a round takes the up to 64 oldest entries, whatever is
+    // not finished goes back to the tail. With HJ_WV_CARRY the queue is NOT drained at the end of a tile: fewer than
+    // 64 entries wait for the next tile's failures, so that every round is dense (draining a tile to completion cost
+    // ~10 sparse rounds per tile, more instructions than all the dense work together -- PMC, profiles/r02_*).
+    auto retry_round = [&]() {
+        const uint32_t take = qCount < 64u ? qCount : 64u;
+        const bool has = lane < take;
+        // lanes >= take read stale-but-in-bounds entries and ignore them
+        const uint32_t at0 = (qHead + lane) & (kWvQCap - 1);
+        uint32_t pos = myQPos[at0], mlo = myQLo[at0], mhi = myQHi[at0];
+        qHead = (qHead + take) & (kWvQCap - 1);
+        qCount -= take;
+        const bool again = round_body(pos, mlo, mhi, has);
+        const unsigned long long am = __ballot(again);
+        if (again) {
+            const uint32_t at = (qHead + qCount + (uint32_t)__popcll(am & ((1ull << lane) - 1ull))) & (kWvQCap - 1);
+            myQPos[at] = pos; myQLo[at] = mlo; myQHi[at] = mhi;
+        }
+        qCount += (uint32_t)__popcll(am);
+        ++rounds;
+    };
+    // to completion: dense rounds while more than a wavefront's worth is queued, then the last <= 64 entries stay in
+    // registers until they are done
+    auto drain = [&]() {
+        while (qCount > 64u) retry_round();
+        bool act = lane < qCount;
+        const uint32_t at0 = (qHead + lane) & (kWvQCap - 1);
+        uint32_t pos = myQPos[at0], mlo = myQLo[at0], mhi = myQHi[at0];
+        qCount = 0;
+        while (__ballot(act)) act = round_body(pos, mlo, mhi, act);
+    };
+
+    // tile t covers chunk offsets [t * kWvTile, ...); lane's tuple j sits at offset t * kWvTile + 64 j + lane
+    // register prefetch, kWvPf tiles deep: the loads are issued unconditionally (lanes past the chunk's end are
+    // masked, not branched around), so the compiler can count them and wait for one tile's loads only
+    Elem nxt[kWvPf][kWvPer];
+    auto issue = [&](Elem (&buf)[kWvPer], uint32_t at) {
+#pragma unroll
+        for (int j = 0; j < kWvPer; ++j) {
+            const uint32_t o = at + lane + 64 * j;
+            buf[j] = o < plen ? Rc[o] : (Elem)0;
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < kWvPf; ++p) issue(nxt[p], (uint32_t)p * kWvTile);
+
+    for (uint32_t tb0 = 0; tb0 < plen; tb0 += kWvPf * kWvTile) {
+#pragma unroll
+      for (int p = 0; p < kWvPf; ++p) {
+        const uint32_t tb = tb0 + (uint32_t)p * kWvTile;
+        if (tb >= plen) break;                                        // wave-uniform
+        uint32_t klo[kWvPer], khi[kWvPer];
+#pragma unroll
+        for (int j = 0; j < kWvPer; ++j) {
+            klo[j] = (uint32_t)nxt[p][j];
+            khi[j] = KEY32 ? 0u : (uint32_t)((uint64_t)nxt[p][j] >> 32);
+        }
+        const bool full = (tb + kWvTile <= clen) & (tb >= kWvOverlap);   // wave-uniform: no head zone, no overlap zone
+        issue(nxt[p], tb + kWvPf * kWvTile);
+        const uint32_t roundsAtTileStart = rounds;
+        (void)roundsAtTileStart;
+        uint32_t liveMask = 0, myMin = kNone, myMaxInv = kNone;       // max kept as min of the complement
+        uint32_t home[kWvPer];
+        // FULL tiles (every position is this chunk's own, no seam zone) skip the zone tests: they are all but the
+        // first and the last one or two tiles of a chunk
+        auto classify = [&](auto fullTag) {
+            constexpr bool FULL = decltype(fullTag)::value;
+#pragma unroll
+            for (int j = 0; j < kWvPer; ++j) {
+                const uint32_t o = tb + lane + 64 * j;
+                const bool in = FULL || (o < clen);                               // counted here
+                const bool okKey = (khi[j] == 0) & (klo[j] != 0);
+                home[j] = (klo[j] >> hshift) & mask32;
+                // inserted here: my tuples, except head-zone stragglers of the previous range; plus the next chunk's
+                // stragglers of MY range in the overlap zone
+                const bool mineHere = FULL || (o < clen ? !((o < kWvOverlap) & (home[j] < loSlot))
+                                                        : ((o < plen) & !lastChunk & (home[j] < limSlot)));
+                const bool ok = mineHere & okKey;
+                inSum += in ? (unsigned long long)wv_pack(khi[j], klo[j]) : 0ull;
+                bad += (in & !okKey) ? 1u : 0u;
+                if constexpr (CHECK) foreign += (in & is_foreign(klo[j], sc)) ? 1u : 0u;
+                liveMask |= ok ? (1u << j) : 0u;
+                myMin = (ok & (home[j] < myMin)) ? home[j] : myMin;
+                myMaxInv = (ok & (~home[j] < myMaxInv)) ? ~home[j] : myMaxInv;
+            }
+        };
+        if (full) classify(std::true_type{}); else classify(std::false_type{});
+        const uint32_t tmin = wave_umin(myMin);                       // kNone: the tile holds no valid tuple
+        if (tmin != kNone) {
+            // The ring moves only as far as it must for the tile's highest home slot (+ a probe walk) to fit, so it
+            // keeps as much history as it can: retry entries carried over from the previous tile are still inside.
+            // It never moves past the tile's lowest home slot (an outlier key is deferred, not the tile).
+            const uint32_t tmax = ~wave_umin(myMaxInv);
+            const uint32_t top = (uint32_t)(((uint64_t)tmax + probeLen + 8u) >> kGranShift) + 1u;
+            uint32_t target = top > kWvGran ? top - kWvGran : 0u;
+            const uint32_t gmin = tmin >> kGranShift;
+            target = target < gmin ? target : gmin;
+            target = target < limG ? target : limG;
+            advance(target);
+        }
+
+        // ---- the PER home-slot attempts of the tile, issued together (independent LDS round trips) ----
+        unsigned long long oldv[kWvPer];
+        uint32_t ownMask = 0;
+        if (HJ_WV_ABL & 1) continue;
+#pragma unroll
+        for (int j = 0; j < kWvPer; ++j) {
+            const bool own = ((liveMask >> j) & 1u) & in_ring(home[j]);
+            ownMask |= own ? (1u << j) : 0u;
+            oldv[j] = kEmpty;
+            if (own)
+                oldv[j] = atomicMin(reinterpret_cast<unsigned long long*>(&win[home[j] & (kWvWin - 1)]),
+                                    (unsigned long long)wv_pack(idx0 + tb + lane + 64 * j, klo[j]));
+        }
+        // ---- whatever did not finish goes to the retry queue, compacted ----
+#pragma unroll
+        for (int j = 0; j < kWvPer; ++j) {
+            while (qCount >= kWvRoundAt) retry_round();                // dense rounds; leaves room for one full step
+            const bool lv = (liveMask >> j) & 1u, own = (ownMask >> j) & 1u;
+            uint32_t mlo = klo[j], mhi = idx0 + tb + lane + 64 * j;
+            const uint64_t mine = wv_pack(mhi, mlo);
+            const bool fail = own & (oldv[j] != kEmpty);               // the slot was taken
+            const bool disp = fail & (oldv[j] > mine);                 // ... by a later tuple: it moves on instead
+            mlo = disp ? (uint32_t)oldv[j] : mlo; mhi = disp ? (uint32_t)(oldv[j] >> 32) : mhi;
+            const uint32_t pos = fail ? ((home[j] + 1) & mask32) : home[j];
+            const bool again = (HJ_WV_ABL & 4) ? false : (fail | (lv & !own));   // outside ring or range: the retry round defers it
+            const unsigned long long am = __ballot(again);
+            if (am) {
+                if (again) {
+                    const uint32_t at = (qHead + qCount + (uint32_t)__popcll(am & ((1ull << lane) - 1ull))) & (kWvQCap - 1);
+                    myQPos[at] = pos; myQLo[at] = mlo; myQHi[at] = mhi;
+                }
+                qCount += (uint32_t)__popcll(am);
+            }
+        }
+#if HJ_WV_CARRY
+        while (qCount >= kWvRoundAt) retry_round();
+        // an entry may wait for company for one tile, not longer (the ring moves on): no round during this tile -> one now
+        if (qCount && rounds == roundsAtTileStart) retry_round();
+#else
+        if (qCount) drain();                                           // before the ring may move on
+#endif
+      }
+    }
+    if (qCount) drain();
+
+    // ---- the rest of the range: what is left in the ring, then empties up to the next chunk's range ----
+    uint32_t endG = limG;
+    if (lastChunk) endG = winLoG + kWvGran < numGran ? winLoG + kWvGran : numGran;
+    advance(endG);
+    if (lane == 0) {
+        if (c == 0) ctr->ownLo = (unsigned long long)loG << kGranShift;
+        if (lastChunk) ctr->ownHiEx = (unsigned long long)winLoG << kGranShift;
+        dcounts[c] = dCount;
+    }
+
+    // counters: one atomic per wavefront
+    unsigned long long c0 = drops, c3 = bad | ((unsigned long long)foreign << 32);
+    const unsigned long long c4 = dCount;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        c0 += __shfl_down(c0, off, 64);
+        dropSum += __shfl_down(dropSum, off, 64);
+        inSum += __shfl_down(inSum, off, 64);
+        c3 += __shfl_down(c3, off, 64);
+    }
+    uint32_t loInv = ~usedLo, hi1 = usedHi1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t a = __shfl_down(loInv, off, 64), b = __shfl_down(hi1, off, 64);
+        loInv = a > loInv ? a : loInv; hi1 = b > hi1 ? b : hi1;
+    }
+    if (lane == 0) {
+        if (c0) atomicAdd(&ctr->conflicts, c0);
+        if (dropSum) atomicAdd(&ctr->conflictSum, dropSum);
+        if (inSum) atomicAdd(&ctr->inputSum, inSum);
+        if (c3 & 0xFFFFFFFFull) atomicAdd(&ctr->badKeys, c3 & 0xFFFFFFFFull);
+        if (c3 >> 32) atomicAdd(&ctr->foreign, c3 >> 32);
+        if (c4) atomicAdd(&ctr->deferred, c4);
+        if (hi1) { atomicMax(&ctr->usedLoInv, (unsigned long long)loInv); atomicMax(&ctr->usedHi1, (unsigned long long)hi1); }
+    }
+}
+
+// Phase B for the sliced deferred queue: chunk c's entries are queue[c * chunkLen .. + dcounts[c]). Same walk as
+// k_build_deferred (hj_build_own.hip): the probe walk of every deferred tuple finished with global atomics. One
+// wavefront per chunk slice at a time, slices dealt round-robin.
+__global__ void __launch_bounds__(kBlock)
+k_wave_deferred(const DeferredEntry* __restrict__ queue, const uint32_t* __restrict__ dcounts, uint32_t nChunks,
+                uint32_t chunkLen, uint64_t* __restrict__ table, uint64_t mask, uint32_t hshift, uint32_t probeLen,
+                Counters* __restrict__ ctr)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t nWaves = gridDim.x * (kBlock / 64), w0 = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    unsigned long long drops = 0, dropSum = 0;
+    for (uint32_t c = w0; c < nChunks; c += nWaves) {
+        const uint32_t cnt = dcounts[c];
+        const DeferredEntry* q = queue + (uint64_t)c * chunkLen;
+        for (uint32_t i = lane; i < cnt; i += 64) {
+            uint64_t mine = q[i].packed;
+            uint64_t pos = q[i].pos;
+            const uint64_t home0 = home_slot((uint32_t)mine, hshift, mask);
+            uint32_t budget = probeLen - (uint32_t)((pos - home0) & mask);
+            for (;;) {
+                if (budget == 0) { drops += 1; dropSum += (uint32_t)mine; break; }
+                const unsigned long long old =
+                    atomicMin(reinterpret_cast<unsigned long long*>(table + pos), (unsigned long long)mine);
+                if (old == kEmpty || old == mine) break;
+                if (old > mine) {
+                    mine = old;
+                    const uint64_t home = home_slot((uint32_t)old, hshift, mask);
+                    budget = probeLen - ((uint32_t)((pos - home) & mask) + 1);
+                } else {
+                    budget -= 1;
+                }
+                pos = (pos + 1) & mask;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        drops += __shfl_down(drops, off, 64);
+        dropSum += __shfl_down(dropSum, off, 64);
+    }
+    if (lane == 0) {
+        if (drops) atomicAdd(&ctr->conflicts, drops);
+        if (dropSum) atomicAdd(&ctr->conflictSum, dropSum);
+    }
+}
+
+// After k_build_wave: the valid slot range (hj_device.h, Counters) = the owned stretch [ownLo, ownHiEx) joined
+// with the blocks deferred tuples start from (+1: a probe walk spills at most probeLen - 1 slots). If it reaches
+// the table's end (walks wrap there) the whole table is made valid.
+__global__ void k_wave_finalize_range(Counters* __restrict__ ctr, uint64_t tableSize)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned long long lo = ctr->ownLo, hiEx = ctr->ownHiEx;
+    const unsigned long long hi1 = ctr->usedHi1;
+    if (hi1) {
+        const unsigned long long dlo = (unsigned long long)(uint32_t)~(uint32_t)ctr->usedLoInv << 9, dhi = (hi1 + 1) << 9;
+        lo = dlo < lo ? dlo : lo; hiEx = dhi > hiEx ? dhi : hiEx;
+    }
+    if (hiEx + 512 >= tableSize) { lo = 0; hiEx = tableSize; }
+    ctr->validLo = lo; ctr->validHiEx = hiEx;
+}
+
+// Slots of the valid range (+512 slots of defined contents past it, + the slack past the table) that no wavefront
+// owned: [validLo, ownLo) and [ownHiEx, validHiEx + 512).
+__global__ void __launch_bounds__(kBlock)
+k_wave_fill_edges(uint64_t* __restrict__ table, const Counters* __restrict__ ctr, uint64_t tableSize)
+{
+    const ulonglong2 e = make_ulonglong2(kEmpty, kEmpty);
+    ulonglong2* t2 = reinterpret_cast<ulonglong2*>(table);
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock, t0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    uint64_t hi = ctr->validHiEx + 512;
+    hi = hi < tableSize ? hi : tableSize;
+    const uint64_t a0 = ctr->validLo >> 1, a1 = ctr->ownLo >> 1;          // all bounds are even (granules / blocks)
+    for (uint64_t v = a0 + t0; v < a1; v += stride) t2[v] = e;
+    const uint64_t b0 = ctr->ownHiEx >> 1, b1 = hi >> 1;
+    for (uint64_t v = b0 + t0; v < b1; v += stride) t2[v] = e;
+    if (blockIdx.x == 0 && threadIdx.x < kTableSlack) table[tableSize + threadIdx.x] = kEmpty;
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+size_t wave_lds_bytes() { return kWvLdsBytes; }
+bool wave_supported(uint64_t tableSize) { return tableSize >= (uint64_t)kWvWin; }
+uint32_t wave_max_chunks(int nCU) { return 16u * (uint32_t)nCU; }
+size_t wave_bounds_bytes(int nCU) { return (4 * (size_t)wave_max_chunks(nCU) + 4) * sizeof(uint32_t); }   // raw, bounds (+1), starts (+1), dcounts
+static uint64_t wave_chunk_len(uint64_t n, int nCU)
+{
+    // one chunk per resident wavefront: a single round of workgroups, no tail
+    const uint32_t maxChunks = wave_max_chunks(nCU);
+    uint64_t chunkLen = (n + maxChunks - 1) / maxChunks;
+    chunkLen = (chunkLen + kWvTile - 1) / kWvTile * kWvTile;
+    return chunkLen < (uint64_t)kWvTile * 4 ? (uint64_t)kWvTile * 4 : chunkLen;
+}
+static uint64_t wave_slice_len(uint64_t chunkLen) { return chunkLen + kWvLook + kWvOverlap; }
+size_t wave_queue_bytes(uint64_t n, int nCU)
+{
+    const uint64_t chunkLen = wave_chunk_len(n, nCU);
+    return (size_t)(((n + chunkLen - 1) / chunkLen) * wave_slice_len(chunkLen) + 64) * sizeof(DeferredEntry);
+}
+
+hipError_t launch_build_wave(const void* R, bool key32, uint64_t n, uint32_t hshift, uint64_t* table, uint64_t tableSize,
+                             uint32_t probeLen, uint64_t idxBase, ShardCheck sc, int nCU, void* boundsBuf, void* queueBuf,
+                             Counters* ctr, hipEvent_t evPhaseA, hipStream_t s)
+{
+    const uint32_t maxChunks = wave_max_chunks(nCU);
+    const uint64_t chunkLen = wave_chunk_len(n, nCU);
+    static_assert(kWvTile * 4 > (int)(kWvLook + kWvOverlap), "a seam may move by less than the shortest chunk");
+    const uint32_t sliceLen = (uint32_t)wave_slice_len(chunkLen);
+    const uint32_t nChunks = (uint32_t)((n + chunkLen - 1) / chunkLen);
+    uint32_t* const raw = static_cast<uint32_t*>(boundsBuf);
+    uint32_t* const bounds = raw + maxChunks;                 // nChunks + 1 entries
+    uint32_t* const starts = bounds + maxChunks + 1;          // nChunks + 1 entries
+    uint32_t* const dcounts = starts + maxChunks + 1;
+    const uint32_t numGran = (uint32_t)(tableSize >> kGranShift);
+    hipError_t e;
+    const dim3 gRaw((nChunks + 1 + kBlock / 64 - 1) / (kBlock / 64)), gMain((nChunks + kWvWaves - 1) / kWvWaves);
+    if (key32) hipLaunchKernelGGL(k_wave_seams<true>, gRaw, dim3(kBlock), 0, s, R, n, (uint32_t)chunkLen, nChunks, tableSize - 1, hshift, starts, raw);
+    else hipLaunchKernelGGL(k_wave_seams<false>, gRaw, dim3(kBlock), 0, s, R, n, (uint32_t)chunkLen, nChunks, tableSize - 1, hshift, starts, raw);
+    hipLaunchKernelGGL(k_wave_bounds_scan, dim3(1), dim3(64), 0, s, raw, nChunks, numGran, bounds);
+#define HJ_WV_LAUNCH(K32, CHK)                                                                                       \
+    hipLaunchKernelGGL((k_build_wave<K32, CHK>), gMain, dim3(kWvThreads), kWvLdsBytes, s, R, n, sliceLen,           \
+                       nChunks, starts, bounds, table, tableSize - 1, hshift, probeLen, idxBase, sc,                         \
+                       static_cast<DeferredEntry*>(queueBuf), dcounts, ctr)
+    if (sc.mask) { if (key32) HJ_WV_LAUNCH(true, true); else HJ_WV_LAUNCH(false, true); }
+    else { if (key32) HJ_WV_LAUNCH(true, false); else HJ_WV_LAUNCH(false, false); }
+#undef HJ_WV_LAUNCH
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (evPhaseA && (e = hipEventRecord(evPhaseA, s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_wave_finalize_range, dim3(1), dim3(64), 0, s, ctr, tableSize);
+    hipLaunchKernelGGL(k_wave_fill_edges, dim3(2048), dim3(kBlock), 0, s, table, ctr, tableSize);
+    hipLaunchKernelGGL(k_wave_deferred, dim3((nChunks + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, s,
+                       static_cast<const DeferredEntry*>(queueBuf), dcounts, nChunks, sliceLen, table, tableSize - 1,
+                       hshift, probeLen, ctr);
+    return hipGetLastError();
+}
+
+}  // namespace hj

@@ -51,7 +51,12 @@ struct Counters {
     unsigned long long usedLoInv, usedHi1;
     unsigned long long validLo, validHiEx;
     unsigned long long foreign;      // tuples of the build / probe inputs that fail the shard check (ShardCheck)
+    // Variant 3 (hj_build_wave.hip): the stretch of the table its wavefronts own and write whole, [ownLo, ownHiEx)
+    unsigned long long ownLo, ownHiEx;
 };
+
+// A tuple that left its LDS window (variants 2 and 3): the slot it had reached and (index << 32 | key)
+struct DeferredEntry { uint64_t pos; uint64_t packed; };
 
 // ---- launch wrappers (defined in hj_kernels.hip) ---------------------------
 // Inputs come in two element formats: 8-byte DataGen tuples (key32 = false; value = key, payload bits must be 0)
@@ -67,22 +72,43 @@ void launch_set_full_range(uint64_t tableSize, Counters* ctr, hipStream_t s);
 // multi-GPU destination split (defined in hj_prj.hip: one order-preserving radix pass, tuples in, keys out);
 // destination = (key >> digitShift) & (nShards - 1)
 size_t shard_work_bytes(uint64_t n, uint32_t nShards);
-void launch_shard_hist(const uint64_t* in, uint64_t n, uint32_t nShards, uint32_t digitShift, void* work,
-                       unsigned long long* counts, hipStream_t s);
-void launch_shard_scatter_ordered(const uint64_t* in, uint64_t n, uint32_t nShards, uint32_t digitShift, void* work,
-                                  uint32_t* outKeys, hipStream_t s);
+hipError_t launch_shard_hist(const uint64_t* in, uint64_t n, uint32_t nShards, uint32_t digitShift, void* work,
+                             unsigned long long* counts, hipStream_t s);
+hipError_t launch_shard_scatter_ordered(const uint64_t* in, uint64_t n, uint32_t nShards, uint32_t digitShift, void* work,
+                                        uint32_t* outKeys, hipStream_t s);
 
 // ---- ownership build (defined in hj_build_own.hip) ---------------------------
 size_t own_queue_bytes(uint64_t rSize);
 size_t own_owner_bytes(uint64_t tableSize);
 bool   own_supported(uint64_t tableSize);
-void launch_sample_locality(const void* R, bool key32, uint64_t n, uint64_t tableSize, uint32_t hshift, uint32_t nSample,
-                            unsigned int* fitCount, hipStream_t s);
+// fitCount[0] = sampled tuples outside variant 2's window, [1] = tuples sampled, [2] = outside variant 3's ring
+hipError_t launch_sample_locality(const void* R, bool key32, uint64_t n, uint64_t tableSize, uint32_t hshift, uint32_t nSample,
+                                  unsigned int* fitCount, hipStream_t s);
+hipError_t own_set_attributes();          // per device, at hj_create
 // phase A (LDS window) -> clear of unowned blocks -> phase B (deferred tuples).
 // Writes every table slot exactly once: no separate launch_fill_empty needed.
-void launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshift, uint64_t* table,
-                      uint64_t tableSize, uint32_t probeLen, uint64_t idxBase, ShardCheck sc, void* ownerBuf, void* queueBuf,
-                      unsigned long long* queueCount, Counters* ctr, hipEvent_t evPhaseA, hipStream_t s);
+hipError_t launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshift, uint64_t* table,
+                            uint64_t tableSize, uint32_t probeLen, uint64_t idxBase, ShardCheck sc, int nCU, void* ownerBuf,
+                            void* queueBuf, unsigned long long* queueCount, Counters* ctr, hipEvent_t evPhaseA, hipStream_t s);
+
+// phase B alone: finishes the queued tuples with global atomics (shared with variant 3)
+void launch_build_deferred(const void* queueBuf, const unsigned long long* queueCount, uint64_t* table, uint64_t tableSize,
+                           uint32_t hshift, uint32_t probeLen, Counters* ctr, hipStream_t s);
+
+// ---- wavefront-private build (defined in hj_build_wave.hip) ------------------
+// geometry the locality sampler (k_sample_locality) needs to predict what k_build_wave would defer
+constexpr uint32_t kWvGranShift = 7;      // retire granule: 128 slots = 1 KiB
+constexpr uint32_t kWvRingGran = 8;       // ring = 8 granules = 1024 slots = 8 KiB per wavefront
+constexpr uint32_t kWvTileTuples = 512;   // tuples per wavefront tile
+size_t wave_lds_bytes();
+bool   wave_supported(uint64_t tableSize);
+size_t wave_bounds_bytes(int nCU);
+size_t wave_queue_bytes(uint64_t n, int nCU);   // deferred queue: one slice per chunk
+// bounds pre-pass -> k_build_wave -> valid range + edge fill -> phase B. queueBuf: own_queue_bytes(n), used as one
+// slice per chunk (a wavefront's deferred tuples go to ITS slice: no atomics in the kernel).
+hipError_t launch_build_wave(const void* R, bool key32, uint64_t n, uint32_t hshift, uint64_t* table, uint64_t tableSize,
+                             uint32_t probeLen, uint64_t idxBase, ShardCheck sc, int nCU, void* boundsBuf, void* queueBuf,
+                             Counters* ctr, hipEvent_t evPhaseA, hipStream_t s);
 
 // ---- PRJ (defined in hj_prj.hip) -------------------------------------------
 struct PrjPlan {
@@ -107,8 +133,9 @@ struct PrjBuffers {
 };
 // Enqueues partition(R), partition(S) and the per-partition LDS join.
 // evPartDone (may be null) is recorded between partitioning and join.
-void launch_prj(const PrjPlan& plan, const PrjBuffers& buf,
-                const uint64_t* R, uint64_t nR, const uint64_t* S, uint64_t nS,
-                Counters* ctr, hipEvent_t evPartDone, hipStream_t s);
+hipError_t launch_prj(const PrjPlan& plan, const PrjBuffers& buf,
+                      const uint64_t* R, uint64_t nR, const uint64_t* S, uint64_t nS, int nCU,
+                      Counters* ctr, hipEvent_t evPartDone, hipStream_t s);
+hipError_t prj_set_attributes();          // per device, at hj_create
 
 }  // namespace hj

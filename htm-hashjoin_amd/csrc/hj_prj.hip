@@ -742,15 +742,16 @@ Work carve(const PrjPlan& pl, void* base)
 
 // One radix pass: in -> out, segments segIn[nSeg+1] -> segOut[nSeg*fan+1].
 // in32: the input already holds bare keys (pass 2); the output always does.
-void run_pass(const void* in, bool in32, uint32_t* out, uint64_t n, const uint32_t* segIn, uint32_t nSeg,
-              uint32_t shift, uint32_t bits, uint32_t* segOut, const Work& w, hipStream_t s)
+hipError_t run_pass(const void* in, bool in32, uint32_t* out, uint64_t n, const uint32_t* segIn, uint32_t nSeg,
+                    uint32_t shift, uint32_t bits, uint32_t* segOut, const Work& w, hipStream_t s)
 {
     const uint32_t fan = 1u << bits;
     const PassLayout l = pass_layout(n, nSeg, fan);
     hipLaunchKernelGGL(k_chunk_base, dim3(1), dim3(64), 0, s, segIn, nSeg, l.chunkLen, w.chunkBase);
     PassParams p{segIn, nSeg, l.chunkLen, w.chunkBase, shift, fan, 0u, 0u};
     // entries past the live chunks must be zero for the scan to be a prefix of live data only
-    hipMemsetAsync(w.hist, 0, sizeof(uint32_t) * l.histEntries, s);
+    const hipError_t e = hipMemsetAsync(w.hist, 0, sizeof(uint32_t) * l.histEntries, s);
+    if (e != hipSuccess) return e;
     if (in32) hipLaunchKernelGGL(k_radix_hist<true>, dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s, in, p, w.hist);
     else hipLaunchKernelGGL(k_radix_hist<false>, dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s, in, p, w.hist);
     hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)l.scanBlocks), dim3(kBlock), 0, s, w.hist, l.histEntries, w.sums);
@@ -765,46 +766,32 @@ void run_pass(const void* in, bool in32, uint32_t* out, uint64_t n, const uint32
                                  in, static_cast<void*>(out), p, w.hist);
     else hipLaunchKernelGGL((k_radix_scatter<false, true, 512, 8, false, 4>), dim3((unsigned)l.maxChunks), dim3(512), 0, s,
                             in, static_cast<void*>(out), p, w.hist);
+    return hipGetLastError();
 }
 
-void partition_relation(const PrjPlan& pl, const Work& w, const uint64_t* in, uint64_t n,
-                        uint32_t* tmp, uint32_t* out, uint32_t* finalOff, hipStream_t s)
+hipError_t partition_relation(const PrjPlan& pl, const Work& w, const uint64_t* in, uint64_t n,
+                              uint32_t* tmp, uint32_t* out, uint32_t* finalOff, hipStream_t s)
 {
     hipLaunchKernelGGL(k_init_seg, dim3(1), dim3(64), 0, s, w.seg0, (uint32_t)n);
-    if (pl.bits2 == 0) {
-        run_pass(in, false, out, n, w.seg0, 1, 0, pl.bits1, finalOff, w, s);
-    } else {
-        run_pass(in, false, tmp, n, w.seg0, 1, 0, pl.bits1, w.seg1, w, s);                         // pass 1, R = 0: tuples -> keys
-        run_pass(tmp, true, out, n, w.seg1, 1u << pl.bits1, pl.bits1, pl.bits2, finalOff, w, s);    // pass 2, R = bits1
-    }
+    if (pl.bits2 == 0) return run_pass(in, false, out, n, w.seg0, 1, 0, pl.bits1, finalOff, w, s);
+    const hipError_t e = run_pass(in, false, tmp, n, w.seg0, 1, 0, pl.bits1, w.seg1, w, s);             // pass 1, R = 0: tuples -> keys
+    if (e != hipSuccess) return e;
+    return run_pass(tmp, true, out, n, w.seg1, 1u << pl.bits1, pl.bits1, pl.bits2, finalOff, w, s);    // pass 2, R = bits1
 }
 }  // namespace
 
-void launch_prj(const PrjPlan& pl, const PrjBuffers& buf, const uint64_t* R, uint64_t nR,
-                const uint64_t* S, uint64_t nS, Counters* ctr, hipEvent_t evPartDone, hipStream_t s)
+hipError_t launch_prj(const PrjPlan& pl, const PrjBuffers& buf, const uint64_t* R, uint64_t nR,
+                      const uint64_t* S, uint64_t nS, int nCU, Counters* ctr, hipEvent_t evPartDone, hipStream_t s)
 {
     const Work w = carve(pl, buf.work);
     uint32_t* const tmp = reinterpret_cast<uint32_t*>(buf.tmpA);
     uint32_t* const partR = reinterpret_cast<uint32_t*>(buf.partR);
     uint32_t* const partS = reinterpret_cast<uint32_t*>(buf.partS);
-    partition_relation(pl, w, R, nR, tmp, partR, w.offR, s);
-    if (S) partition_relation(pl, w, S, nS, tmp, partS, w.offS, s);
-    if (evPartDone) hipEventRecord(evPartDone, s);
+    hipError_t e = partition_relation(pl, w, R, nR, tmp, partR, w.offR, s);
+    if (e != hipSuccess) return e;
+    if (S && (e = partition_relation(pl, w, S, nS, tmp, partS, w.offS, s)) != hipSuccess) return e;
+    if (evPartDone && (e = hipEventRecord(evPartDone, s)) != hipSuccess) return e;
     const uint32_t P = 1u << pl.radixBits;
-    static bool attrSet = false;
-    if (!attrSet) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_prj_join<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kJoinSlots * sizeof(uint32_t));
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_prj_join<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kJoinSlots * sizeof(uint32_t));
-        attrSet = true;
-    }
-    static int nCU = 0;
-    if (!nCU) {
-        int dev = 0;
-        nCU = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&nCU, hipDeviceAttributeMultiprocessorCount, dev);
-    }
     const unsigned grid = P < (uint32_t)nCU ? P : (unsigned)nCU;   // one persistent workgroup per CU
     static_assert(kJoinSlots * 2 == 65536, "two 16-bit counters per LDS word cover every 16-bit key remainder");
     if (pl.radixBits >= 16)
@@ -815,6 +802,7 @@ void launch_prj(const PrjPlan& pl, const PrjBuffers& buf, const uint64_t* R, uin
         hipLaunchKernelGGL(k_prj_join<false>, dim3(grid), dim3(kJoinThreads), kJoinSlots * sizeof(uint32_t), s,
                        (const uint32_t*)partR, w.offR, S ? (const uint32_t*)partS : nullptr, w.offS, pl.radixBits, P, (uint32_t)nR,
                        (uint32_t)(S ? nS : 1), ctr);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
@@ -960,40 +948,49 @@ size_t shard_work_bytes(uint64_t n, uint32_t nShards)
            align_up(sizeof(uint32_t) * l.histEntries, 256) + align_up(sizeof(uint32_t) * (l.scanBlocks + 1), 256);
 }
 
-void launch_shard_hist(const uint64_t* in, uint64_t n, uint32_t nShards, uint32_t digitShift, void* work,
-                       unsigned long long* counts, hipStream_t s)
+hipError_t launch_shard_hist(const uint64_t* in, uint64_t n, uint32_t nShards, uint32_t digitShift, void* work,
+                             unsigned long long* counts, hipStream_t s)
 {
     const ShardWork w = shard_carve(work, n, nShards);
     const PassLayout l = pass_layout(n, 1, nShards);
     hipLaunchKernelGGL(k_init_seg, dim3(1), dim3(64), 0, s, w.seg0, (uint32_t)n);
     hipLaunchKernelGGL(k_chunk_base, dim3(1), dim3(64), 0, s, w.seg0, 1u, l.chunkLen, w.chunkBase);
     PassParams p{w.seg0, 1u, l.chunkLen, w.chunkBase, digitShift & 0xFFu, nShards, (digitShift >> 8) & 1u, 1u};
-    (void)hipMemsetAsync(w.hist, 0, sizeof(uint32_t) * l.histEntries, s);
+    const hipError_t e = hipMemsetAsync(w.hist, 0, sizeof(uint32_t) * l.histEntries, s);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_radix_hist<false>, dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s, static_cast<const void*>(in), p, w.hist);
     hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)l.scanBlocks), dim3(kBlock), 0, s, w.hist, l.histEntries, w.sums);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, s, w.sums, (uint32_t)l.scanBlocks);
     hipLaunchKernelGGL(k_scan_add, dim3((unsigned)l.scanBlocks), dim3(kBlock), 0, s, w.hist, l.histEntries, w.sums);
     hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(kBlock), 0, s, p, w.hist, (uint32_t)n, w.segOut);
     hipLaunchKernelGGL(k_shard_counts, dim3(1), dim3(64), 0, s, w.segOut, nShards, counts);
+    return hipGetLastError();
 }
 
 // tuples in, bare keys out, stable: the exchange moves 4 bytes per tuple and no index
-void launch_shard_scatter_ordered(const uint64_t* in, uint64_t n, uint32_t nShards, uint32_t digitShift, void* work,
-                                  uint32_t* outKeys, hipStream_t s)
+hipError_t launch_shard_scatter_ordered(const uint64_t* in, uint64_t n, uint32_t nShards, uint32_t digitShift, void* work,
+                                        uint32_t* outKeys, hipStream_t s)
 {
     const ShardWork w = shard_carve(work, n, nShards);
     const PassLayout l = pass_layout(n, 1, nShards);
     PassParams p{w.seg0, 1u, l.chunkLen, w.chunkBase, digitShift & 0xFFu, nShards, (digitShift >> 8) & 1u, 1u};
     const size_t lds = sizeof(uint32_t) * ((size_t)nShards * kStabGroups + kStabTile + (kStabTile >> 5) + 1);   // <= 65.1 KiB
-    static bool attrSet = false;
-    if (!attrSet) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_shard_scatter_stable),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  sizeof(uint32_t) * (kStabMaxFan * kStabGroups + kStabTile + (kStabTile >> 5) + 1));
-        attrSet = true;
-    }
     hipLaunchKernelGGL(k_shard_scatter_stable, dim3((unsigned)l.maxChunks), dim3(kStabThreads), lds, s,
                        in, outKeys, p, w.hist);
+    return hipGetLastError();
+}
+
+hipError_t prj_set_attributes()
+{
+    // per device (hj_create calls this with its device current): the LDS join table and the stable split's staging
+    hipError_t e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_prj_join<false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, kJoinSlots * sizeof(uint32_t))) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_prj_join<true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, kJoinSlots * sizeof(uint32_t))) != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_shard_scatter_stable),
+                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                               sizeof(uint32_t) * (kStabMaxFan * kStabGroups + kStabTile + (kStabTile >> 5) + 1));
 }
 
 }  // namespace hj

@@ -74,7 +74,11 @@ typedef struct {
                                  R partition fits one LDS table)                */
     uint32_t buildVariant;    /* 0 = auto (samples R for locality, like the pre-round of
                                  HTMHashBuild.hpp:100-154); 1 = global atomicMin kernel;
-                                 2 = block-ownership + LDS-window kernel          */
+                                 2 = block-ownership + workgroup LDS-window kernel (locality
+                                 up to a shuffle window of ~2000 positions);
+                                 3 = wavefront-private LDS rings over statically owned slot
+                                 ranges (tight locality, the reference's default
+                                 --shuffleRange 16); all give the same table            */
     uint32_t reserved[5];
 } hj_params;
 
