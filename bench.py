@@ -40,13 +40,18 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the other_workloads legs")
     ap.add_argument("--cpu-sample-log2n", type=int, default=27)
-    ap.add_argument("--build-variant", type=int, default=0, help="0 auto, 1 global atomics, 2 LDS window")
+    ap.add_argument("--build-variant", type=int, default=0,
+                    help="0 auto, 1 global atomics, 2 workgroup LDS window, 3 wavefront LDS rings")
     ap.add_argument("--strong", action="store_true", help="N>1: split the N=1 total instead of 2^log2n per GPU")
-    ap.add_argument("--other-split", action="store_true",
-                    help="N>1: also time a few steps with the split that was NOT chosen and report them as other_split")
-    ap.add_argument("--split", default="auto", choices=["auto", "low", "high"],
-                    help="N>1: destination = low key bits, high key bits (range split), or auto = high when >= 3/4 of "
-                         "every rank's tuples stay put under it (sharded.py)")
+    ap.add_argument("--no-other-split", action="store_true",
+                    help="N>1: skip the few extra steps with the split that was NOT chosen (reported as other_split)")
+    ap.add_argument("--split", default="low", choices=["auto", "low", "high"],
+                    help="N>1: destination = low key bits (default: BASELINE config 4's all-to-all, (G-1)/G of the tuples "
+                         "cross xGMI), high key bits (range split), or auto = high when >= 3/4 of every rank's tuples stay "
+                         "put under it (sharded.py)")
+    ap.add_argument("--exchange", default="p2p", choices=["p2p", "a2a"],
+                    help="N>1: batch of pairwise isend/irecv per relation, or one all_to_all_single per relation "
+                         "(falls back to p2p for a step whose largest per-peer message is >= 512 MiB)")
     return ap.parse_args()
 
 

@@ -124,7 +124,7 @@ class ShardedJoin:
 
     ONE_BASED = 0x100                   # HJ_SHARD_ONE_BASED: split on (key - 1)
 
-    def __init__(self, engine, torch, dist, rank, world, split="low", max_key=None):
+    def __init__(self, engine, torch, dist, rank, world, split="low", max_key=None, exchange="p2p"):
         """split: which key bits pick the destination (both relations use the same).
              "low"   key & (G-1): balanced whatever the keys are, but moves (G-1)/G of a relation that is held as
                      contiguous key ranges
@@ -132,16 +132,26 @@ class ShardedJoin:
                      stays where it is
              "auto"  "high" if at least 3/4 of the tuples of every rank would stay under it, else "low" -- the
                      reference's idea of exploiting locality where the data has it, applied to the exchange
-           max_key: upper bound of the keys (DataGen: the relation size); found by one all-reduce if not given."""
+           max_key: upper bound of the keys (DataGen: the relation size); found by one all-reduce if not given.
+           exchange: "p2p" = one batch of direct pairwise isend/irecv per relation in messages of <= max_msg_tuples;
+                     "a2a" = ONE all_to_all_single per relation (the collective BASELINE config 4 names) whenever no
+                     per-peer message of the step exceeds max_msg_tuples on any rank, else the p2p batch for that step
+                     (this RCCL build delivered half of a >= 2 GiB per-peer message, tools/dbg/a2a_check.py). Both
+                     deliver the same bytes to the same places; which is faster on xGMI is for the first multi-GPU
+                     run to say (bench.py --exchange)."""
         self.e, self.torch, self.dist, self.rank, self.world = engine, torch, dist, rank, world
         if split not in ("low", "high", "auto"):
             raise ValueError(f"split must be low, high or auto, got {split!r}")
-        self.split, self.max_key = split, max_key
+        if exchange not in ("p2p", "a2a"):
+            raise ValueError(f"exchange must be p2p or a2a, got {exchange!r}")
+        self.split, self.max_key, self.exchange = split, max_key, exchange
         self.mode = None                # decided on the first step: digit position (| ONE_BASED)
         self.shift = 0                  # home-slot shift of the local tables: log2 G for the low-bit split
         self.last = {}
         self._keep = None
         self._in_place_hint = False     # the previous step found every tuple already on its rank
+        self._step_max_msg = 0          # largest single message of the current step over all ranks (keys)
+        self.last_exchange_form = None  # "all_to_all_single" / "batch_isend_irecv" of the last exchange that ran
 
     def _all_reduce_scalar(self, v, op):
         if self.dist is None or self.world == 1:
@@ -174,7 +184,12 @@ class ShardedJoin:
             self.mode, self.shift = high if self._all_reduce_scalar(ok, "MIN") else low
 
     def _exchange_counts(self, cnt_r, cnt_s):
-        both = self.torch.cat([cnt_r, cnt_s]).reshape(2, self.world).t().contiguous()   # [dest][R,S]
+        """One small all_to_all_single: row d of `both` = (R tuples, S tuples I send to rank d, my largest message).
+        Returns my send counts, my receive counts, and the largest single message of the step over ALL ranks (every rank
+        computes the same value from what it received, so the choice between the two exchange forms needs no
+        collective of its own)."""
+        big = self.torch.maximum(cnt_r.max(), cnt_s.max()).reshape(1).expand(self.world)
+        both = self.torch.stack([cnt_r, cnt_s, big], dim=1).contiguous()                   # [dest][R, S, big]
         recv = self.torch.empty_like(both)
         if self.dist is not None:
             self.dist.all_to_all_single(recv.view(-1), both.view(-1))
@@ -182,6 +197,7 @@ class ShardedJoin:
             recv.copy_(both)
         send = both.cpu().tolist()
         got = recv.cpu().tolist()
+        self._step_max_msg = max(g[2] for g in got)
         return [s[0] for s in send], [s[1] for s in send], [g[0] for g in got], [g[1] for g in got]
 
     # Largest single message, in keys. RCCL (ROCm 7.0 wheel of torch 2.10) delivered only half of an
@@ -190,11 +206,22 @@ class ShardedJoin:
     max_msg_tuples = 1 << 27
 
     def _exchange_async(self, send, send_counts, recv_counts):
-        """Starts the exchange of one relation: direct pairwise sends (every peer at once, so all xGMI links
-        carry traffic; no ring), batched into one group. Returns (output tensor, work handles). With NCCL/RCCL
-        the transfers run on the backend's stream behind the kernels already enqueued on the current stream,
-        and work.wait() only makes the current stream wait (no host block)."""
+        """Starts the exchange of one relation and returns (output tensor, work handles). With NCCL/RCCL the transfers
+        run on the backend's stream behind the kernels already enqueued on the current stream, and work.wait() only
+        makes the current stream wait (no host block). The receiver lays the pieces out in source-rank order."""
         out = self.e.empty_keys(sum(recv_counts))
+        if self.dist is None or self.world == 1:
+            out.copy_(send)
+            return out, []
+        if self.exchange == "a2a" and self._step_max_msg <= self.max_msg_tuples:
+            # the scatter output is grouped by destination, the receive buffer by source: exactly all_to_all_single's
+            # layout, one collective call, my own share copied inside it
+            w = self.dist.all_to_all_single(out, send, output_split_sizes=list(recv_counts),
+                                            input_split_sizes=list(send_counts), async_op=True)
+            self.last_exchange_form = "all_to_all_single"
+            return out, [w]
+        # direct pairwise sends (every peer at once, so all xGMI links carry traffic; no ring), batched into one group
+        self.last_exchange_form = "batch_isend_irecv"
         so = [0]
         for c in send_counts:
             so.append(so[-1] + c)
@@ -205,33 +232,38 @@ class ShardedJoin:
         if recv_counts[me]:
             out[ro[me]:ro[me + 1]].copy_(send[so[me]:so[me + 1]])           # my own share never leaves the GPU
         works = []
-        if self.dist is not None and self.world > 1:
-            step = self.max_msg_tuples
-            ops = []
-            for off in range(1, self.world):                                  # staggered peer order
-                d = (me + off) % self.world
-                for k in range(0, send_counts[d], step):
-                    ops.append(self.dist.P2POp(self.dist.isend, send[so[d] + k: so[d] + min(k + step, send_counts[d])], d))
-                src = (me - off) % self.world
-                for k in range(0, recv_counts[src], step):
-                    ops.append(self.dist.P2POp(self.dist.irecv, out[ro[src] + k: ro[src] + min(k + step, recv_counts[src])], src))
-            if ops:
-                works = self.dist.batch_isend_irecv(ops)
+        step = self.max_msg_tuples
+        ops = []
+        for off in range(1, self.world):                                  # staggered peer order
+            d = (me + off) % self.world
+            for k in range(0, send_counts[d], step):
+                ops.append(self.dist.P2POp(self.dist.isend, send[so[d] + k: so[d] + min(k + step, send_counts[d])], d))
+            src = (me - off) % self.world
+            for k in range(0, recv_counts[src], step):
+                ops.append(self.dist.P2POp(self.dist.irecv, out[ro[src] + k: ro[src] + min(k + step, recv_counts[src])], src))
+        if ops:
+            works = self.dist.batch_isend_irecv(ops)
         return out, works
 
     def _try_in_place(self, r_local, s_local, table_size):
         """Optimistic step after one that moved nothing: join the pieces in place with the shard check riding on the
         build and probe kernels (no histogram pass, no split); accept if no rank saw a foreign tuple, else report
         False and let the caller run the full path (the table is rebuilt there)."""
-        if not (self._in_place_hint and self.world > 1 and self.shift == 0 and table_size == 2 * r_local.numel()):
+        # _in_place_hint, world and shift are the same on every rank (they come out of collectives); whether MY piece
+        # fits the table is not -- a rank whose piece does not still takes part in the all-reduce below (it reports a
+        # foreign tuple), so every rank makes the same collective calls whatever its piece looks like
+        if not (self._in_place_hint and self.world > 1 and self.shift == 0):
             return False
         e = self.e
-        e.set_check(self.world, self.mode, self.rank)
-        e.reserve(table_size, r_local.numel(), s_local.numel())
-        e.build_tuples(r_local)
-        e.probe_tuples(s_local)
-        foreign = e.foreign()
-        e.set_check(0)
+        fits = table_size == 2 * r_local.numel()
+        foreign = 1
+        if fits:
+            e.set_check(self.world, self.mode, self.rank)
+            e.reserve(table_size, r_local.numel(), s_local.numel())
+            e.build_tuples(r_local)
+            e.probe_tuples(s_local)
+            foreign = e.foreign()
+            e.set_check(0)
         if self._all_reduce_scalar(foreign, "SUM") != 0:
             self._in_place_hint = False
             return False
@@ -257,8 +289,11 @@ class ShardedJoin:
         send_r, send_s, recv_r, recv_s = self._exchange_counts(cnt_r, cnt_s)
         split_name = "low key bits" if self.mode == 0 else f"high key bits (range split, digit at bit {self.mode & 0xFF})"
         moved = sum(send_r) - send_r[self.rank] + sum(send_s) - send_s[self.rank]
-        if self.world > 1 and self.shift == 0 and table_size == 2 * r_local.numel() and \
-                self._all_reduce_scalar(moved, "SUM") == 0:
+        # world and shift are global, the piece's size is not: it goes INTO the reduced value instead of deciding
+        # whether this rank calls the collective (round-1 ADVICE: a mismatched collective with ragged pieces)
+        stay = self.world > 1 and self.shift == 0 and \
+            self._all_reduce_scalar(moved + (0 if table_size == 2 * r_local.numel() else 1), "SUM") == 0
+        if stay:
             # a range split under which every tuple already sits on its rank: nothing to regroup, nothing to send --
             # the rank's piece IS its shard, in input order
             e.reserve(table_size, r_local.numel(), s_local.numel())
@@ -283,6 +318,53 @@ class ShardedJoin:
                      "recv_r": got_r.numel(), "recv_s": got_s.numel(), "split": split_name}
         self._keep = (out_r, out_s, got_r, got_s)   # alive until the stream has consumed them
 
+    def step_phases(self, r_local, s_local, table_size):
+        """One step with the phases run one after the other (device synchronised and all ranks at a barrier between
+        them) and timed on the host: what the overlapped step() hides is visible here. Returns milliseconds per phase;
+        exchange_* is the time from all ranks having their send buffers ready to all of this rank's pieces having
+        arrived. Only for a split that really exchanges (not the in-place shortcut)."""
+        e, ph = self.e, {}
+        self._keep = None
+        if self.mode is None:
+            self._decide_split(r_local, s_local)
+
+        def lap(name, t0):
+            e.sync()
+            ph[name] = ph.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
+            if self.dist is not None and self.world > 1:
+                self.dist.barrier()
+            return time.perf_counter()
+
+        e.sync()
+        t = lap("_", time.perf_counter())
+        cnt_r = e.histogram(r_local, self.world, self.mode)
+        cnt_s = e.histogram(s_local, self.world, self.mode)
+        t = lap("histogram", t)
+        send_r, send_s, recv_r, recv_s = self._exchange_counts(cnt_r, cnt_s)
+        t = lap("counts", t)
+        out_r = e.scatter(r_local, self.world, cnt_r, self.mode)
+        out_s = e.scatter(s_local, self.world, cnt_s, self.mode)
+        t = lap("split", t)
+        got_r, work = self._exchange_async(out_r, send_r, recv_r)
+        for w in work:
+            w.wait()
+        t = lap("exchange_r", t)
+        got_s, work = self._exchange_async(out_s, send_s, recv_s)
+        for w in work:
+            w.wait()
+        t = lap("exchange_s", t)
+        e.reserve(table_size, got_r.numel(), got_s.numel())
+        e.build(got_r, self.shift, table_size)
+        t = lap("build", t)
+        e.probe(got_s)
+        t = lap("probe", t)
+        del ph["_"]
+        self.last = {"sent_r": sum(send_r) - send_r[self.rank], "sent_s": sum(send_s) - send_s[self.rank],
+                     "recv_r": got_r.numel(), "recv_s": got_s.numel(),
+                     "split": "low key bits" if self.mode == 0 else f"high key bits (range split, digit at bit {self.mode & 0xFF})"}
+        self._keep = (out_r, out_s, got_r, got_s)
+        return ph
+
     def result(self):
         r = self.e.finish()
         keys = ("conflicts", "totalMatches", "inputSum", "tableSumFull", "conflictSum", "buildDeferred")
@@ -302,11 +384,12 @@ def _local_roofline(res):
     beside it as ms_per_step - local kernels): k_build_own over the received keys, 4 B read + 8 B slot written per
     R tuple; only when the LDS-window build ran."""
     loc, ex = res["local"], res["exchange"]
-    if loc["buildVariant"] != 2 or not loc["buildPhaseA_us"]:
+    if loc["buildVariant"] not in (2, 3) or not loc["buildPhaseA_us"]:
         return None
     nbytes = 12.0 * ex["recv_r"]
     gbps = nbytes / (loc["buildPhaseA_us"] * 1e-6) / 1e9
-    return {"bound": "hbm", "kernel": "k_build_own<keys> (rank 0, last step)", "achieved": gbps, "peak": 8000.0,
+    kname = "k_build_wave" if loc["buildVariant"] == 3 else "k_build_own"
+    return {"bound": "hbm", "kernel": kname + "<keys> (rank 0, last step)", "achieved": gbps, "peak": 8000.0,
             "unit": "GB/s", "frac": gbps / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": nbytes,
             "launch_us": loc["buildPhaseA_us"]}
 
@@ -330,19 +413,32 @@ def squeeze_into_range(v, n, lo, width, np):
     return v + np.uint64(lo + 1)
 
 
-def bench_sharded(args, torch, dist, hj, rank, world, local_rank):
-    """bench.py's N > 1 leg. Default = WEAK scaling: every rank holds 2^log2n tuples of R and of S (the N=1
-    workload per GPU; 8 GPUs x 2^30 = BASELINE config 4); --strong keeps the N=1 total and splits it.
+def bench_sharded(args, torch, dist, hj, rank, world, local_rank, engine=None, device=None):
+    """bench.py's N > 1 leg = BASELINE config 4: radix join across the GPUs of one node with an all-to-all partition
+    exchange. Default = WEAK scaling: every rank holds 2^log2n tuples of R and of S (the N=1 workload per GPU; 8 GPUs x
+    2^30 = config 4); --strong keeps the N=1 total and splits it.
+
+    `value` is measured with the LOW-BIT split (destination = key & (G-1), HASH_BIT_MODULO of
+    mc/src/parallel_radix_join.c:59): (G-1)/G of every relation really crosses xGMI in every step. The range split
+    (--split high / auto), under which the bench's contiguous near-sorted pieces hardly move and the ranks end up
+    joining in place, is timed for a few steps beside it and reported as `other_split` -- it says what exploiting the
+    data's locality in the exchange is worth, it is not the config-4 number. `phase_ms` / `exchange_ms` / `local_ms`
+    come from extra steps whose phases run one after the other (step_phases): exchange and local time separately, as
+    SURVEY.md 8e asks.
+
     Globally the relation is the near-sorted one the reference generates, cut into contiguous pieces: rank g's
     piece = DataGen over its own key range, drawn piecewise (a rank cannot afford the serial rand() stream of its
     neighbours). Keys are 32 bits: while world * n <= 2^32 - 1 rank g owns the keys (g*n, (g+1)*n]; beyond that
     (8 x 2^30 tuples, 2^32 keys) the key space is cut into `world` equal contiguous ranges and a rank's n draws are
     squeezed into its range -- every key about world*n / 2^32 times, duplicates adjacent, as in a globally sorted
-    relation with more tuples than keys."""
+    relation with more tuples than keys.
+
+    engine / device: the CPU tests pass a checker-backed engine and "cpu" to run this very function under gloo."""
     strip = _log2(world)
     n = (1 << args.log2n) >> (strip if args.strong else 0)          # tuples per rank and relation
     window = args.shuffle_range
     wrap = (1 << 32) - 1
+    dev = device or f"cuda:{local_rank}"
     lo, width = rank_key_range(world, n, rank)
     R = hj.generate_data(args.dist, n, n, window)                    # values in [1, n] (uniform and the unique-key kinds)
 
@@ -350,18 +446,22 @@ def bench_sharded(args, torch, dist, hj, rank, world, local_rank):
         if args.dist == "random":                                    # 31-bit random keys: no range to speak of
             return v
         return squeeze_into_range(v, n, lo, width, np)
-    r_local = torch.from_numpy(to_range(R).view("int64")).to(f"cuda:{local_rank}")
+    r_local = torch.from_numpy(to_range(R).view("int64")).to(dev)
     # S as main.cpp:91-97 builds it: sorted 1..N on the same key range (for `random`: R itself)
     S = R.copy() if args.dist == "random" else to_range(np.arange(1, n + 1, dtype=np.uint64))
-    s_local = torch.from_numpy(S.view("int64")).to(f"cuda:{local_rank}")
+    s_local = torch.from_numpy(S.view("int64")).to(dev)
     del R, S
-    eng = HipShardEngine(hj, torch, local_rank, build_variant=args.build_variant)
+    eng = engine if engine is not None else HipShardEngine(hj, torch, local_rank, build_variant=args.build_variant)
     table_size = 2 * n
     total_keys = min(world * n, wrap)                                # the keys lie in [1, relation size] (or the whole key space)
+    exchange = getattr(args, "exchange", "p2p")
+
+    def new_job(split):
+        return ShardedJoin(eng, torch, dist, rank, world, split=split,
+                           max_key=None if args.dist == "random" else total_keys, exchange=exchange)
 
     def timed(split, steps, warmup):
-        job = ShardedJoin(eng, torch, dist, rank, world, split=split,
-                          max_key=None if args.dist == "random" else total_keys)
+        job = new_job(split)
         for _ in range(warmup):
             job.step(r_local, s_local, table_size)
         eng.sync(); dist.barrier(); eng.sync()
@@ -370,18 +470,26 @@ def bench_sharded(args, torch, dist, hj, rank, world, local_rank):
             job.step(r_local, s_local, table_size)
         eng.sync(); dist.barrier(); eng.sync()
         dt = time.perf_counter() - t0
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return job, float(t.item())
 
     job, dt = timed(args.split, args.steps, args.warmup)
     res = job.result()
     total = 2 * n * world
-    # the same join with the other split, a few steps, for the record (not part of `value`); on request only: the
-    # default run should not depend on the large point-to-point exchange when the chosen split does not need it
+    # exchange and local time separately: a few steps with the phases run one after the other, maximum over ranks
+    phase_ms = None
+    if world > 1 and "in place" not in res["exchange"]["split"]:
+        pj = new_job(args.split)
+        runs = [pj.step_phases(r_local, s_local, table_size) for _ in range(3)][1:]      # the first one warms up
+        names = list(runs[0])
+        t = torch.tensor([[r_[k] for k in names] for r_ in runs], dtype=torch.float64, device=dev).min(dim=0).values
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        phase_ms = dict(zip(names, (float(x) for x in t.tolist())))
+    # the same join with the other split, a few steps, for the record (never part of `value`)
     alt = None
-    if world > 1 and args.other_split:
-        other = "high" if job.mode == 0 else "low"
+    if world > 1 and not getattr(args, "no_other_split", False):
+        other = "auto" if job.mode == 0 else "low"
         k = max(1, min(3, args.steps))
         ajob, adt = timed(other, k, 1)
         ares = ajob.result()
@@ -401,7 +509,7 @@ def bench_sharded(args, torch, dist, hj, rank, world, local_rank):
                                f"({n * world} in total), dataDistr={args.dist} W={window}, every rank holding one contiguous "
                                f"piece of the near-sorted relations; destination = {res['exchange']['split']} (--split "
                                f"{args.split}); step = destination histogram + stable split to 32-bit keys + all-to-all "
-                               "(R and S, overlapped) + local table build/probe",
+                               f"(R and S, overlapped with split and build; --exchange {exchange}) + local table build/probe",
                    "algo": "atomic", "rSize": n * world,
                    "sSize": n * world, "per_gpu_rSize": n, "dataDistr": args.dist, "shuffleRange": window,
                    "parallelism": f"radix{world}"},
@@ -409,10 +517,16 @@ def bench_sharded(args, torch, dist, hj, rank, world, local_rank):
         "checks": {"matches_plus_conflicts_eq_rSize": (res["totalMatches"] + res["conflicts"] == n * world) if unique_domain else None,
                    "unique_keys_all_match": (res["totalMatches"] == n * world) if unique else None,
                    "tableSum_plus_conflictSum_eq_inputSum": res["tableSumFull"] + res["conflictSum"] == res["inputSum"]},
-        "exchange": res["exchange"], "local_kernel_us": {k: res["local"][k] for k in ("clear_us", "build_us", "probe_us")},
+        "exchange": {**res["exchange"], "form": job.last_exchange_form,
+                     "bytes_sent_per_rank_per_step": 4 * (res["exchange"]["sent_r"] + res["exchange"]["sent_s"])},
+        "phase_ms": phase_ms,
+        "exchange_ms": (phase_ms["exchange_r"] + phase_ms["exchange_s"]) if phase_ms else None,
+        "local_ms": (sum(v for k_, v in phase_ms.items() if not k_.startswith("exchange"))) if phase_ms else None,
+        "local_kernel_us": {k: res["local"][k] for k in ("clear_us", "build_us", "probe_us")},
         "local_build_variant": res["local"]["buildVariant"],
         "other_split": alt,
         "roofline": _local_roofline(res), "cpu_baseline": None,
     }
-    eng.close()
+    if engine is None:
+        eng.close()
     return line

@@ -40,14 +40,21 @@ class LoopbackDist:
     def barrier(self):
         self.hub.bar.wait()
 
-    def all_to_all_single(self, out, inp):
+    def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None, async_op=False):
         h, w = self.hub, self.hub.world
-        h.slots[self.rank] = inp
+        isz = list(input_split_sizes) if input_split_sizes is not None else [inp.numel() // w] * w
+        osz = list(output_split_sizes) if output_split_sizes is not None else [out.numel() // w] * w
+        h.slots[self.rank] = (inp, isz)
         h.bar.wait()
-        k = inp.numel() // w
+        at = 0
         for s in range(w):
-            out[s * k:(s + 1) * k].copy_(h.slots[s][self.rank * k:(self.rank + 1) * k])
+            src, ssz = h.slots[s]
+            off = sum(ssz[:self.rank])
+            assert ssz[self.rank] == osz[s], (s, self.rank, ssz, osz)
+            out[at:at + osz[s]].copy_(src[off:off + osz[s]])
+            at += osz[s]
         h.bar.wait()
+        return _Work() if async_op else None
 
     def all_reduce(self, t, op="SUM"):
         h = self.hub

@@ -534,7 +534,8 @@ def test_range_split_on_one_gpu(dist, window):
 
 @pytest.mark.parametrize("world,dist,window,split,expect", [
     (2, "uniform", 16, "low", "low"), (4, "uniform", 16, "auto", "high"), (2, "uniform", 16, "high", "high"),
-    (4, "shuffle", 16, "auto", "low"), (2, "sorted", 16, "auto", "in place"), (4, "local_shuffle", 1024, "auto", "high")])
+    (4, "shuffle", 16, "auto", "low"), (2, "sorted", 16, "auto", "in place"), (4, "local_shuffle", 1024, "auto", "high"),
+    (4, "uniform", 16, "low", "low a2a")])
 def test_sharded_join_product_engine_in_process_ranks(world, dist, window, split, expect):
     """htm_hashjoin_amd/sharded.py end to end with the PRODUCT engine (HipShardEngine) at world 2 and 4 on one GPU: the
     ranks are threads of this process and exchange through tests/loopback_dist.py instead of RCCL. Low-bit split, range
@@ -553,14 +554,18 @@ def test_sharded_join_product_engine_in_process_ranks(world, dist, window, split
     def run(rank):
         try:
             eng = HipShardEngine(hj, torch, 0)
-            job = ShardedJoin(eng, torch, LoopbackDist(hub, rank), rank, world, split=split, max_key=n)
-            job.max_msg_tuples = 5000                                     # several messages per peer
+            a2a = expect.endswith("a2a")                                  # one all_to_all_single per relation instead
+            job = ShardedJoin(eng, torch, LoopbackDist(hub, rank), rank, world, split=split, max_key=n,
+                              exchange="a2a" if a2a else "p2p")
+            if not a2a:
+                job.max_msg_tuples = 5000                                 # several messages per peer
             r_local = torch.from_numpy(R[rank * n_local:(rank + 1) * n_local].view(np.int64).copy()).to("cuda:0")
             s_local = torch.from_numpy(S[rank * n_local:(rank + 1) * n_local].view(np.int64).copy()).to("cuda:0")
             for _ in range(2):                                            # second step: buffers are reused
                 job.step(r_local, s_local, 2 * n_local)
             res = job.result()
             res["mode"] = job.mode
+            res["form"] = job.last_exchange_form
             out[rank] = res
             eng.close()
         except Exception as e:                                            # noqa: BLE001 -- reported by the main thread
@@ -575,8 +580,9 @@ def test_sharded_join_product_engine_in_process_ranks(world, dist, window, split
     assert not errs, errs
     got = out[0]
     bits = (n - 1).bit_length() - (world.bit_length() - 1)
-    if expect == "low":
+    if expect.startswith("low"):
         assert got["mode"] == 0 and got["exchange"]["sent_r"] > 0
+        assert got["form"] == ("all_to_all_single" if expect.endswith("a2a") else "batch_isend_irecv")
         want = oracle.sharded_reference(R, S, world)
     else:
         assert got["mode"] == (bits | hj.SHARD_ONE_BASED)
