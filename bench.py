@@ -83,10 +83,13 @@ def time_steps(torch, dist_mod, world, fn, steps, warmup):
     return dt
 
 
-def oa_leg(torch, hj, ctx, n, dist, window, steps, warmup, S_dev=None, variant=0):
-    """Open-addressing build+probe on one GPU. Returns (result dict, S_dev)."""
+def oa_leg(torch, hj, ctx, n, dist, window, steps, warmup, S_dev=None, variant=0, keep=None):
+    """Open-addressing build+probe on one GPU. Returns (result dict, S_dev). keep: a list that receives the host R
+    (the CPU baseline joins the same relation afterwards)."""
     R = hj.generate_data(dist, n, n, window)
     R_dev = to_device(R, torch, "cuda")
+    if keep is not None:
+        keep.append(R)
     del R
     if S_dev is None:
         S_dev = torch.arange(1, n + 1, dtype=torch.int64, device="cuda")   # generate_data("sorted"), main.cpp:93
@@ -142,20 +145,50 @@ def prj_leg(torch, hj, ctx, n, dist, window, steps, warmup, S_dev):
         "partition_us": res["partition_us"], "join_us": res["join_us"],
         "totalMatches": res["totalMatches"],
         "hbm_frac_of_32B_per_tuple": 32.0 * 2 * n / (dt / steps) / 1e9 / HBM_PEAK_GBPS,
+        # dominant kernel of the radix join: the pass-1 scatter (tuples in, keys out: 8 B read + 4 B written per tuple),
+        # HIP-event timed on the launch stream for R's launch (hj_result.prjScatterPass1R_us)
+        "roofline": {"bound": "hbm", "kernel": "k_radix_scatter (pass 1, R)", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+                     "algorithmic_bytes_per_launch": 12.0 * n, "launch_us": res["prjScatterPass1R_us"],
+                     "achieved": 12.0 * n / (res["prjScatterPass1R_us"] * 1e-6) / 1e9 if res["prjScatterPass1R_us"] else None,
+                     "frac": 12.0 * n / (res["prjScatterPass1R_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS if res["prjScatterPass1R_us"] else None,
+                     "traffic": None},
         "checks": {"matches_eq_n": res["totalMatches"] == n},
     }
 
 
-def cpu_baseline(hj, log2n, dist, window):
-    """The oracle's threaded port (oracle/hj_oracle.c: orc_build_probe_mt) on the host cores:
-    same distribution at 2^log2n tuples (the reference's own experiment size), 64 chunks as
-    in parallel_for(blocked_range(0, rSize, rSize/64)), min(64, cores) threads."""
+def effective_cpus():
+    """CPUs this process may really use: its affinity mask, capped by the cgroup's CPU quota (a GPU box hands a
+    container 16 of the host's 64+ CPUs; os.cpu_count() would report the host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], int(txt[1])
+            else:
+                quota, period = txt[0], int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1") and int(quota) > 0:
+                n = min(n, max(1, -(-int(quota) // period)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
+def cpu_baseline(hj, log2n, dist, window, R=None):
+    """The oracle's threaded port (oracle/hj_oracle.c: orc_build_probe_mt) on the host cores: the SAME relation the
+    GPU leg joined when R is handed over (the metric's 2^30), else the same distribution at 2^log2n; 64 chunks as in
+    parallel_for(blocked_range(0, rSize, rSize/64)), min(64, effective CPUs) threads. A few seconds of CPU work."""
     from oracle import oracle   # checker/baseline only
-    n = 1 << log2n
-    cores = os.cpu_count() or 1
+    cores = effective_cpus()
     threads = min(64, cores)
-    R = hj.generate_data(dist, n, n, window)
-    S = hj.generate_data("sorted", n)
+    if R is None:
+        n = 1 << log2n
+        R = hj.generate_data(dist, n, n, window)
+    n = R.size
+    log2n = n.bit_length() - 1
+    import numpy as np
+    S = np.arange(1, n + 1, dtype=np.uint64)              # generate_data("sorted"), main.cpp:93
     best = None
     for _ in range(3):
         r = oracle.build_probe_mt(R, S, 4, 64, threads, atomic=True)
@@ -164,8 +197,9 @@ def cpu_baseline(hj, log2n, dist, window):
     rn = oracle.build_probe_mt(R, S, 4, 64, threads, atomic=False)
     return {
         "value": 2 * n / best, "unit": "Mtuples/s", "cores": threads, "kind": "port",
-        "sample": f"atomic (CAS) build+probe, {dist} W={window}, |R|=|S|=2^{log2n}, best of 3; "
-                  f"nocc (racy store) same input: {2 * n / (rn['build_us'] + rn['probe_us']):.0f} Mtuples/s",
+        "sample": f"atomic (CAS) build+probe on the relation the GPU leg joined, {dist} W={window}, |R|=|S|=2^{log2n}, "
+                  f"best of 3, {threads} threads on {cores} effective CPUs (affinity + cgroup quota; os.cpu_count() = "
+                  f"{os.cpu_count()}); nocc (racy store) same input: {2 * n / (rn['build_us'] + rn['probe_us']):.0f} Mtuples/s",
     }
 
 
@@ -180,7 +214,7 @@ def cpu_baseline_prj(log2n):
     if not os.path.exists(exe):
         return None
     n = 1 << log2n
-    threads = min(64, os.cpu_count() or 1)
+    threads = min(64, effective_cpus())
     try:
         us = None
         for _ in range(2):       # best of 2: the host share of a GPU box is a noisy place
@@ -231,7 +265,8 @@ def main():
 
     stream = torch.cuda.current_stream().cuda_stream
     ctx = hj.HashJoinContext(local_rank, stream=stream)
-    main_leg, S_dev = oa_leg(torch, hj, ctx, n, a.dist, a.shuffle_range, a.steps, a.warmup, variant=a.build_variant)
+    host_R = [] if not a.no_cpu_baseline else None
+    main_leg, S_dev = oa_leg(torch, hj, ctx, n, a.dist, a.shuffle_range, a.steps, a.warmup, variant=a.build_variant, keep=host_R)
 
     # roofline of the dominant kernel (the build): algorithmic bytes = 16 B per R tuple
     # (8 read + 8 slot write), duration = HIP-event time of that launch
@@ -249,20 +284,22 @@ def main():
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc) and a.log2n == 30 and a.dist == "uniform":
         traffic = json.load(open(pmc)).get(dom_name)      # HBM bytes per launch from rocprofv3 PMC passes (same command)
-    step_bytes = 48.0 * n      # clear 16 + build 16 + probe 16 per (R,S) tuple pair
+    # Whole step in SURVEY.md 8d's accounting: 16 B per R tuple (read 8 + slot written 8) + 16 B per S tuple (read 8 +
+    # home slot 8) = 32 B per tuple pair. The table clear is NOT a separate 16 B: the LDS builds write every reachable
+    # slot exactly once, empties included (PMC round 1: build group 17.3 GB at 2^30, not 34 GB).
+    step_bytes = 32.0 * n
     roofline = {"bound": "hbm", "kernel": dom_name,
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg, "launch_us": dom_us,
                 "other_kernels": {
-                    "build_group_us (bounds pre-pass + LDS build kernel + edge/unowned clear + deferred phase)" if v2 else "k_fill_empty_us":
+                    "build_group_us (seam/bounds pre-pass + LDS build kernel + edge/unowned clear + deferred phase)" if v2 else "k_fill_empty_us":
                         ku["build_us"] if v2 else ku["clear_us"],
                     "k_probe_us": ku["probe_us"], "k_probe_GBps": 16.0 * n / (ku["probe_us"] * 1e-6) / 1e9,
-                    "k_sample_locality_plus_readback_us": ku["clear_us"] if v2 else None},
-                "whole_step": {"algorithmic_bytes": step_bytes, "GBps": step_bytes / (main_leg["ms_per_step"] * 1e-3) / 1e9,
-                               "frac": step_bytes / (main_leg["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                               "frac_reference_accounting_16B_per_tuple_no_clear":
-                                   32.0 * n / (main_leg["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
+                    "k_sample_locality_us (the pre-round decides on the device: no host read-back)": ku["clear_us"] if v2 else None},
+                "whole_step": {"algorithmic_bytes": step_bytes, "bytes_per_tuple_pair": 32,
+                               "GBps": step_bytes / (main_leg["ms_per_step"] * 1e-3) / 1e9,
+                               "frac": step_bytes / (main_leg["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
 
     extra = {}
     if not a.no_extra:
@@ -283,7 +320,8 @@ def main():
 
     cpu = cpu_prj = None
     if not a.no_cpu_baseline:
-        cpu = cpu_baseline(hj, min(a.cpu_sample_log2n, a.log2n), a.dist, a.shuffle_range)
+        cpu = cpu_baseline(hj, a.log2n, a.dist, a.shuffle_range, R=host_R[0] if host_R else None)
+        del host_R
         cpu_prj = cpu_baseline_prj(min(a.cpu_sample_log2n, a.log2n))
 
     line = {
@@ -293,7 +331,8 @@ def main():
         "dtype": "u64 tuples (u32 key), integer", "data": "synthetic (DataGen restatement, srand(0) glibc stream)",
         "config": {"workload": f"open-addressing build+probe (atomic), |R|=|S|=2^{a.log2n}, dataDistr={a.dist} "
                                f"W={a.shuffle_range}, S=sorted, probeLength=4, tableSize=2|R|; "
-                               "step = table clear + build + probe, inputs resident in HBM",
+                               "step = build (locality pre-round; every reachable slot written once, empties included: "
+                               "no separate table clear) + probe, inputs resident in HBM",
                    "algo": "atomic", "rSize": n, "sSize": n, "dataDistr": a.dist, "shuffleRange": a.shuffle_range},
         "result": {k: main_leg[k] for k in ("conflicts", "totalMatches", "inputSum", "buildVariant",
                                             "buildDeferred", "checks")},

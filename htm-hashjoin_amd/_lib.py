@@ -48,7 +48,7 @@ class hj_result(C.Structure):
         + [(n, C.c_double) for n in (
             "clear_us", "build_us", "probe_us", "partition_us", "join_us", "total_us", "h2d_us")]
         + [("buildDeferred", C.c_uint64), ("buildPhaseA_us", C.c_double), ("algoUsed", C.c_uint32),
-           ("reserved0", C.c_uint32), ("foreignTuples", C.c_uint64)]
+           ("reserved0", C.c_uint32), ("foreignTuples", C.c_uint64), ("prjScatterPass1R_us", C.c_double)]
     )
 
     def as_dict(self):

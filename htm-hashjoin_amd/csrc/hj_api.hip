@@ -15,7 +15,7 @@
 using namespace hj;
 
 namespace {
-enum Ev { EV_CLEAR0, EV_BUILD0, EV_BUILD_A, EV_BUILD1, EV_PROBE0, EV_PROBE1, EV_PRJ0, EV_PRJ_PART, EV_PRJ1, EV_COUNT };
+enum Ev { EV_CLEAR0, EV_BUILD0, EV_BUILD_A, EV_BUILD1, EV_PROBE0, EV_PROBE1, EV_PRJ0, EV_PRJ_PART, EV_PRJ1, EV_PRJ_S0, EV_PRJ_S1, EV_COUNT };
 }
 
 struct hj_ctx {
@@ -273,7 +273,9 @@ int hj_reserve(hj_ctx* c, const hj_params* params, uint64_t rSize, uint64_t sSiz
     return HJ_OK;
 }
 
-// Locality pre-round: 256 sample tiles of R. Answer = the build kernel worth taking:
+// Locality pre-round, host-side form (hj_join_dev with HJ_ALGO_AUTO only: the choice between table join and radix join
+// changes which buffers and kernels are used at all, so it is read back; hj_build_dev decides on the device, see
+// build_common). 256 sample tiles of R. Answer = the build kernel worth taking:
 //   3  the wavefront-private rings (hj_build_wave.hip) if at most 1/128 of the sampled tuples would fall outside
 //      their ring (tight locality: the reference's default shuffle window of 16, anything up to ~100 positions);
 //   2  the workgroup window (hj_build_own.hip) if it would have to defer at most 1/12 of the tuples (measured at
@@ -287,10 +289,7 @@ static int sample_variant(hj_ctx* c, const void* d, bool key32, uint64_t n, uint
     HJ_HIP(c, launch_sample_locality(d, key32, n, tableSize, hshift, nSample, c->fitCount, c->stream));
     HJ_HIP(c, hipMemcpyAsync(c->hFit, c->fitCount, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
     HJ_HIP(c, hipStreamSynchronize(c->stream));
-    const uint64_t outOwn = c->hFit[0], seen = c->hFit[1], outWave = c->hFit[2];
-    if (canWave && outWave * 128 <= seen) *variant = 3;
-    else if (canOwn && outOwn * 12 <= seen) *variant = 2;
-    else *variant = 1;
+    *variant = variant_for_sample(c->hFit[0], c->hFit[1], c->hFit[2], canOwn, canWave);
     return HJ_OK;
 }
 
@@ -312,28 +311,50 @@ static int build_common(hj_ctx* c, const void* d, bool key32, uint64_t n, uint32
     const bool canWave = n && wave_supported(tableSize) && c->capQueue >= wave_queue_bytes(n, c->nCU);
     if (variant == 3 && !canWave) variant = canOwn ? 2 : 1;
     if (variant == 2 && !canOwn) variant = 1;
-    if (variant == 0) {
-        variant = 1;
-        if ((canOwn || canWave) && (rc = sample_variant(c, d, key32, n, tableSize, hshift, canOwn, canWave, &variant))) return rc;
-    }
-    c->variantUsed = variant;
+    if (variant == 0 && !canOwn && !canWave) variant = 1;
+    c->variantUsed = variant;                    // 0: decided on the device, reported from Counters::variant
     c->algoUsed = c->params.algo == HJ_ALGO_AUTO ? (uint32_t)HJ_ALGO_ATOMIC : c->params.algo;
-    if (variant == 3) {
+    const uint32_t pl = probe_len(c->params);
+    if (variant == 0) {
+        // The locality pre-round decides ON THE DEVICE (this call stays asynchronous: no read-back). The kernels of
+        // every candidate variant are enqueued behind it, each gated on the word the pre-round writes; the ones not
+        // chosen return at once (~2 us each, less than the host round trip they replace). Order: the LDS builds
+        // first, so that EV_BUILD_A still brackets the phase-A kernel of whichever of them runs.
+        HJ_HIP(c, launch_sample_locality(d, key32, n, tableSize, hshift, 256, c->fitCount, c->stream));
+        launch_pick_variant(c->fitCount, canOwn, canWave, c->dCtr, c->stream);
+        HJ_HIP(c, hipGetLastError());
         if ((rc = record(c, EV_BUILD0))) return rc;
-        HJ_HIP(c, launch_build_wave(d, key32, n, hshift, c->table, tableSize, probe_len(c->params), idxBase, c->sc, c->nCU,
-                                    c->boundsBuf, c->queueBuf, c->dCtr, c->ev[EV_BUILD_A], c->stream));
+        const unsigned long long* word = &c->dCtr->variant;
+        // phase A of both LDS variants, EV_BUILD_A, then their tails: the event brackets the phase-A kernel of
+        // whichever runs (plus one empty launch)
+        for (int parts = 1; parts <= 2; ++parts) {
+            if (canWave)
+                HJ_HIP(c, launch_build_wave(d, key32, n, hshift, c->table, tableSize, pl, idxBase, c->sc, c->nCU, c->boundsBuf,
+                                            c->queueBuf, c->dCtr, Gate{word, 3}, parts, nullptr, c->stream));
+            if (canOwn)
+                HJ_HIP(c, launch_build_own(d, key32, n, hshift, c->table, tableSize, pl, idxBase, c->sc, c->nCU, c->ownerBuf,
+                                           c->queueBuf, c->queueCount, c->dCtr, Gate{word, 2}, parts, nullptr, c->stream));
+            if (parts == 1 && (rc = record(c, EV_BUILD_A))) return rc;
+        }
+        launch_fill_empty(c->table, tableSize + kTableSlack, Gate{word, 1}, c->stream);
+        launch_set_full_range(tableSize, c->dCtr, Gate{word, 1}, c->stream);
+        launch_build_atomic_min(d, key32, n, c->table, tableSize, hshift, pl, idxBase, c->sc, c->dCtr, Gate{word, 1}, c->stream);
+    } else if (variant == 3) {
+        if ((rc = record(c, EV_BUILD0))) return rc;
+        HJ_HIP(c, launch_build_wave(d, key32, n, hshift, c->table, tableSize, pl, idxBase, c->sc, c->nCU,
+                                    c->boundsBuf, c->queueBuf, c->dCtr, Gate{nullptr, 0}, 3, c->ev[EV_BUILD_A], c->stream));
         c->evSet[EV_BUILD_A] = true;
     } else if (variant == 2) {
         if ((rc = record(c, EV_BUILD0))) return rc;
-        HJ_HIP(c, launch_build_own(d, key32, n, hshift, c->table, tableSize, probe_len(c->params), idxBase, c->sc, c->nCU,
-                                   c->ownerBuf, c->queueBuf, c->queueCount, c->dCtr, c->ev[EV_BUILD_A], c->stream));
+        HJ_HIP(c, launch_build_own(d, key32, n, hshift, c->table, tableSize, pl, idxBase, c->sc, c->nCU,
+                                   c->ownerBuf, c->queueBuf, c->queueCount, c->dCtr, Gate{nullptr, 0}, 3, c->ev[EV_BUILD_A], c->stream));
         c->evSet[EV_BUILD_A] = true;
     } else {
-        launch_fill_empty(c->table, tableSize + kTableSlack, c->stream);
-        launch_set_full_range(tableSize, c->dCtr, c->stream);
+        launch_fill_empty(c->table, tableSize + kTableSlack, Gate{nullptr, 0}, c->stream);
+        launch_set_full_range(tableSize, c->dCtr, Gate{nullptr, 0}, c->stream);
         HJ_HIP(c, hipGetLastError());
         if ((rc = record(c, EV_BUILD0))) return rc;
-        if (n) launch_build_atomic_min(d, key32, n, c->table, tableSize, hshift, probe_len(c->params), idxBase, c->sc, c->dCtr, c->stream);
+        if (n) launch_build_atomic_min(d, key32, n, c->table, tableSize, hshift, pl, idxBase, c->sc, c->dCtr, Gate{nullptr, 0}, c->stream);
     }
     HJ_HIP(c, hipGetLastError());
     if ((rc = record(c, EV_BUILD1))) return rc;
@@ -411,8 +432,9 @@ int hj_prj_join_dev(hj_ctx* c, const uint64_t* dR, uint64_t rSize, const uint64_
     int rc;
     if ((rc = record(c, EV_PRJ0))) return rc;
     PrjBuffers buf{c->tmpA, c->partR, c->partS, c->work};
-    HJ_HIP(c, launch_prj(pl, buf, dR, rSize, dS, dS ? sSize : 0, c->nCU, c->dCtr, c->ev[EV_PRJ_PART], c->stream));
-    c->evSet[EV_PRJ_PART] = true;
+    HJ_HIP(c, launch_prj(pl, buf, dR, rSize, dS, dS ? sSize : 0, c->nCU, c->dCtr, c->ev[EV_PRJ_PART], c->ev[EV_PRJ_S0],
+                         c->ev[EV_PRJ_S1], c->stream));
+    c->evSet[EV_PRJ_PART] = c->evSet[EV_PRJ_S0] = c->evSet[EV_PRJ_S1] = true;
     if ((rc = record(c, EV_PRJ1))) return rc;
     HJ_HIP(c, hipGetLastError());
     c->prjRan = true;
@@ -483,6 +505,7 @@ int hj_fetch_result(hj_ctx* c, hj_result* out)
         out->partition_us = elapsed_us(c, EV_PRJ0, EV_PRJ_PART);
         out->join_us = elapsed_us(c, EV_PRJ_PART, EV_PRJ1);
         out->total_us = elapsed_us(c, EV_PRJ0, EV_PRJ1);
+        out->prjScatterPass1R_us = elapsed_us(c, EV_PRJ_S0, EV_PRJ_S1);
     } else {
         out->conflicts = k.conflicts;
         out->conflictSum = k.conflictSum;
@@ -490,7 +513,7 @@ int hj_fetch_result(hj_ctx* c, hj_result* out)
         out->tableSumHalf = k.tableSumHalf;
         out->tableSumFull = k.tableSumFull;
         out->outputSum = (c->params.algo == HJ_ALGO_NOCC ? k.tableSumHalf : k.tableSumFull) + k.conflictSum;
-        out->buildVariant = c->variantUsed;
+        out->buildVariant = c->variantUsed ? c->variantUsed : (uint32_t)k.variant;   // 0: the device chose
         out->buildDeferred = k.deferred;
         out->buildPhaseA_us = elapsed_us(c, EV_BUILD0, EV_BUILD_A);
         out->clear_us = elapsed_us(c, EV_CLEAR0, EV_BUILD0);

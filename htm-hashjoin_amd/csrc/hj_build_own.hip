@@ -98,8 +98,9 @@ __global__ void __launch_bounds__(kOwnThreads, 4)
 k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
             uint64_t* __restrict__ table, uint64_t mask, uint32_t hshift, uint32_t probeLen, uint64_t idxBase, ShardCheck sc,
             unsigned int* __restrict__ owner, DeferredEntry* __restrict__ queue,
-            unsigned long long* __restrict__ queueCount, Counters* __restrict__ ctr)
+            unsigned long long* __restrict__ queueCount, Counters* __restrict__ ctr, Gate gate)
 {
+    if (gate_closed(gate)) return;
     extern __shared__ __align__(16) uint64_t win[];   // kWinSlots slots, ring indexed by (slot & (kWinSlots-1))
     __shared__ unsigned int owned[kWinBlocks];   // per ring block: 0 = not tried yet, 1 = claimed by this workgroup, 2 = someone else's
     __shared__ unsigned int need[kWinBlocks];    // per ring block: wanted by the current tile (count, or 0x10000 = unconditional)
@@ -421,9 +422,9 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
 // at most probeLen-1 slots past a home slot), probes may read one block further, so blocks [lo, hi+2]
 // are given defined contents and home slots in [lo*512, (hi+2)*512) are probed. If that reaches the
 // table end (probe walks wrap there) the whole table is made valid.
-__global__ void k_finalize_range(Counters* __restrict__ ctr, uint32_t numBlocks, uint64_t tableSize)
+__global__ void k_finalize_range(Counters* __restrict__ ctr, uint32_t numBlocks, uint64_t tableSize, Gate gate)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x != 0 || blockIdx.x != 0 || gate_closed(gate)) return;
     const unsigned long long hi1 = ctr->usedHi1;
     if (hi1 == 0) { ctr->validLo = 0; ctr->validHiEx = 0; return; }          // nothing inserted anywhere
     const unsigned long long lo = (unsigned long long)(uint32_t)~(uint32_t)ctr->usedLoInv;
@@ -436,8 +437,9 @@ __global__ void k_finalize_range(Counters* __restrict__ ctr, uint32_t numBlocks,
 // Blocks outside [validLo, validHiEx + 512) are never read, so they are not written either.
 __global__ void __launch_bounds__(kBlock)
 k_clear_unowned(uint64_t* __restrict__ table, const unsigned int* __restrict__ owner, const Counters* __restrict__ ctr,
-                uint32_t numBlocks, uint64_t tableSize)
+                uint32_t numBlocks, uint64_t tableSize, Gate gate)
 {
+    if (gate_closed(gate)) return;
     const ulonglong2 e = make_ulonglong2(kEmpty, kEmpty);
     const uint32_t b0 = (uint32_t)(ctr->validLo >> kBlkShift);
     uint32_t b1 = (uint32_t)(ctr->validHiEx >> kBlkShift) + 1;     // exclusive; one block past the probed range
@@ -466,8 +468,9 @@ k_clear_unowned(uint64_t* __restrict__ table, const unsigned int* __restrict__ o
 __global__ void __launch_bounds__(kBlock)
 k_build_deferred(const DeferredEntry* __restrict__ queue, const unsigned long long* __restrict__ queueCount,
                  uint64_t* __restrict__ table, uint64_t mask, uint32_t hshift, uint32_t probeLen,
-                 Counters* __restrict__ ctr)
+                 Counters* __restrict__ ctr, Gate gate)
 {
+    if (gate_closed(gate)) return;
     const unsigned long long nq = *queueCount;
     unsigned long long drops = 0, dropSum = 0;
     for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < nq;
@@ -603,10 +606,12 @@ hipError_t own_set_attributes()
 
 hipError_t launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshift, uint64_t* table,
                             uint64_t tableSize, uint32_t probeLen, uint64_t idxBase, ShardCheck sc, int nCU, void* ownerBuf,
-                            void* queueBuf, unsigned long long* queueCount, Counters* ctr, hipEvent_t evPhaseA, hipStream_t s)
+                            void* queueBuf, unsigned long long* queueCount, Counters* ctr, Gate gate, int parts,
+                            hipEvent_t evPhaseA, hipStream_t s)
 {
     const uint32_t numBlocks = (uint32_t)(tableSize >> kBlkShift);
     hipError_t e;
+    if (parts & 1) {
     if ((e = hipMemsetAsync(ownerBuf, 0, own_owner_bytes(tableSize), s)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(queueCount, 0, sizeof(unsigned long long), s)) != hipSuccess) return e;
     // one chunk per resident workgroup (2 per CU: 76 KiB LDS each): a single wave of workgroups, no tail,
@@ -619,24 +624,36 @@ hipError_t launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshi
 #define HJ_OWN_LAUNCH(K32, CHK)                                                                                      \
     hipLaunchKernelGGL((k_build_own<K32, CHK>), dim3(grid), dim3(kOwnThreads), kWinSlots * sizeof(uint64_t), s,       \
                        R, n, chunkLen, table, tableSize - 1, hshift, probeLen, idxBase, sc,                            \
-                       static_cast<unsigned int*>(ownerBuf), static_cast<DeferredEntry*>(queueBuf), queueCount, ctr)
+                       static_cast<unsigned int*>(ownerBuf), static_cast<DeferredEntry*>(queueBuf), queueCount, ctr, gate)
     if (sc.mask) { if (key32) HJ_OWN_LAUNCH(true, true); else HJ_OWN_LAUNCH(false, true); }   // the instances that count foreign tuples
     else { if (key32) HJ_OWN_LAUNCH(true, false); else HJ_OWN_LAUNCH(false, false); }
 #undef HJ_OWN_LAUNCH
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (evPhaseA && (e = hipEventRecord(evPhaseA, s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_finalize_range, dim3(1), dim3(64), 0, s, ctr, numBlocks, tableSize);
+    }
+    if (!(parts & 2)) return hipSuccess;
+    hipLaunchKernelGGL(k_finalize_range, dim3(1), dim3(64), 0, s, ctr, numBlocks, tableSize, gate);
     hipLaunchKernelGGL(k_clear_unowned, dim3(2048), dim3(kBlock), 0, s, table,
-                       static_cast<const unsigned int*>(ownerBuf), ctr, numBlocks, tableSize);
-    launch_build_deferred(queueBuf, queueCount, table, tableSize, hshift, probeLen, ctr, s);
+                       static_cast<const unsigned int*>(ownerBuf), ctr, numBlocks, tableSize, gate);
+    launch_build_deferred(queueBuf, queueCount, table, tableSize, hshift, probeLen, ctr, gate, s);
     return hipGetLastError();
 }
 
 void launch_build_deferred(const void* queueBuf, const unsigned long long* queueCount, uint64_t* table, uint64_t tableSize,
-                           uint32_t hshift, uint32_t probeLen, Counters* ctr, hipStream_t s)
+                           uint32_t hshift, uint32_t probeLen, Counters* ctr, Gate gate, hipStream_t s)
 {
     hipLaunchKernelGGL(k_build_deferred, dim3(1024), dim3(kBlock), 0, s,
-                       static_cast<const DeferredEntry*>(queueBuf), queueCount, table, tableSize - 1, hshift, probeLen, ctr);
+                       static_cast<const DeferredEntry*>(queueBuf), queueCount, table, tableSize - 1, hshift, probeLen, ctr, gate);
+}
+
+__global__ void k_pick_variant(const unsigned int* __restrict__ fit, bool canOwn, bool canWave, Counters* __restrict__ ctr)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) ctr->variant = variant_for_sample(fit[0], fit[1], fit[2], canOwn, canWave);
+}
+
+void launch_pick_variant(const unsigned int* fitCount, bool canOwn, bool canWave, Counters* ctr, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_pick_variant, dim3(1), dim3(64), 0, s, fitCount, canOwn, canWave, ctr);
 }
 
 }  // namespace hj

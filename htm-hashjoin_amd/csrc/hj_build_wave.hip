@@ -114,8 +114,9 @@ constexpr uint32_t kWvOverlap = HJ_WV_OVERLAP;
 template <bool KEY32>
 __global__ void __launch_bounds__(kBlock)
 k_wave_seams(const void* __restrict__ Rv, uint64_t n, uint32_t chunkLen, uint32_t nChunks, uint64_t mask,
-             uint32_t hshift, uint32_t* __restrict__ starts, uint32_t* __restrict__ raw)
+             uint32_t hshift, uint32_t* __restrict__ starts, uint32_t* __restrict__ raw, Gate gate)
 {
+    if (gate_closed(gate)) return;
     using Elem = typename std::conditional<KEY32, uint32_t, uint64_t>::type;
     const Elem* __restrict__ R = static_cast<const Elem*>(Rv);
     const uint32_t lane = threadIdx.x & 63;
@@ -154,8 +155,9 @@ k_wave_seams(const void* __restrict__ Rv, uint64_t n, uint32_t chunkLen, uint32_
 // bounds[c] = max over chunks <= c of raw (chunks without a valid sample inherit), bounds[nChunks] = the table's
 // end. One wavefront: 64 chunks per step, prefix maximum by shuffles.
 __global__ void __launch_bounds__(64)
-k_wave_bounds_scan(const uint32_t* __restrict__ raw, uint32_t nChunks, uint32_t numGran, uint32_t* __restrict__ bounds)
+k_wave_bounds_scan(const uint32_t* __restrict__ raw, uint32_t nChunks, uint32_t numGran, uint32_t* __restrict__ bounds, Gate gate)
 {
+    if (gate_closed(gate)) return;
     const uint32_t lane = threadIdx.x;
     // the first valid sample opens the first range (nothing below it is owned)
     uint32_t first = kNone;
@@ -187,8 +189,9 @@ __global__ void __launch_bounds__(kWvThreads, 4)
 k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_t nChunks, const uint32_t* __restrict__ starts,
              const uint32_t* __restrict__ bounds, uint64_t* __restrict__ table, uint64_t mask, uint32_t hshift,
              uint32_t probeLen, uint64_t idxBase, ShardCheck sc, DeferredEntry* __restrict__ queue,
-             uint32_t* __restrict__ dcounts, Counters* __restrict__ ctr)
+             uint32_t* __restrict__ dcounts, Counters* __restrict__ ctr, Gate gate)
 {
+    if (gate_closed(gate)) return;
     extern __shared__ __align__(16) uint64_t lds[];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t c = blockIdx.x * kWvWaves + wave;
@@ -479,8 +482,9 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
 __global__ void __launch_bounds__(kBlock)
 k_wave_deferred(const DeferredEntry* __restrict__ queue, const uint32_t* __restrict__ dcounts, uint32_t nChunks,
                 uint32_t chunkLen, uint64_t* __restrict__ table, uint64_t mask, uint32_t hshift, uint32_t probeLen,
-                Counters* __restrict__ ctr)
+                Counters* __restrict__ ctr, Gate gate)
 {
+    if (gate_closed(gate)) return;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t nWaves = gridDim.x * (kBlock / 64), w0 = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     unsigned long long drops = 0, dropSum = 0;
@@ -522,9 +526,9 @@ k_wave_deferred(const DeferredEntry* __restrict__ queue, const uint32_t* __restr
 // After k_build_wave: the valid slot range (hj_device.h, Counters) = the owned stretch [ownLo, ownHiEx) joined
 // with the blocks deferred tuples start from (+1: a probe walk spills at most probeLen - 1 slots). If it reaches
 // the table's end (walks wrap there) the whole table is made valid.
-__global__ void k_wave_finalize_range(Counters* __restrict__ ctr, uint64_t tableSize)
+__global__ void k_wave_finalize_range(Counters* __restrict__ ctr, uint64_t tableSize, Gate gate)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x != 0 || blockIdx.x != 0 || gate_closed(gate)) return;
     unsigned long long lo = ctr->ownLo, hiEx = ctr->ownHiEx;
     const unsigned long long hi1 = ctr->usedHi1;
     if (hi1) {
@@ -538,8 +542,9 @@ __global__ void k_wave_finalize_range(Counters* __restrict__ ctr, uint64_t table
 // Slots of the valid range (+512 slots of defined contents past it, + the slack past the table) that no wavefront
 // owned: [validLo, ownLo) and [ownHiEx, validHiEx + 512).
 __global__ void __launch_bounds__(kBlock)
-k_wave_fill_edges(uint64_t* __restrict__ table, const Counters* __restrict__ ctr, uint64_t tableSize)
+k_wave_fill_edges(uint64_t* __restrict__ table, const Counters* __restrict__ ctr, uint64_t tableSize, Gate gate)
 {
+    if (gate_closed(gate)) return;
     const ulonglong2 e = make_ulonglong2(kEmpty, kEmpty);
     ulonglong2* t2 = reinterpret_cast<ulonglong2*>(table);
     const uint64_t stride = (uint64_t)gridDim.x * kBlock, t0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -574,7 +579,7 @@ size_t wave_queue_bytes(uint64_t n, int nCU)
 
 hipError_t launch_build_wave(const void* R, bool key32, uint64_t n, uint32_t hshift, uint64_t* table, uint64_t tableSize,
                              uint32_t probeLen, uint64_t idxBase, ShardCheck sc, int nCU, void* boundsBuf, void* queueBuf,
-                             Counters* ctr, hipEvent_t evPhaseA, hipStream_t s)
+                             Counters* ctr, Gate gate, int parts, hipEvent_t evPhaseA, hipStream_t s)
 {
     const uint32_t maxChunks = wave_max_chunks(nCU);
     const uint64_t chunkLen = wave_chunk_len(n, nCU);
@@ -588,23 +593,26 @@ hipError_t launch_build_wave(const void* R, bool key32, uint64_t n, uint32_t hsh
     const uint32_t numGran = (uint32_t)(tableSize >> kGranShift);
     hipError_t e;
     const dim3 gRaw((nChunks + 1 + kBlock / 64 - 1) / (kBlock / 64)), gMain((nChunks + kWvWaves - 1) / kWvWaves);
-    if (key32) hipLaunchKernelGGL(k_wave_seams<true>, gRaw, dim3(kBlock), 0, s, R, n, (uint32_t)chunkLen, nChunks, tableSize - 1, hshift, starts, raw);
-    else hipLaunchKernelGGL(k_wave_seams<false>, gRaw, dim3(kBlock), 0, s, R, n, (uint32_t)chunkLen, nChunks, tableSize - 1, hshift, starts, raw);
-    hipLaunchKernelGGL(k_wave_bounds_scan, dim3(1), dim3(64), 0, s, raw, nChunks, numGran, bounds);
+    if (parts & 1) {
+    if (key32) hipLaunchKernelGGL(k_wave_seams<true>, gRaw, dim3(kBlock), 0, s, R, n, (uint32_t)chunkLen, nChunks, tableSize - 1, hshift, starts, raw, gate);
+    else hipLaunchKernelGGL(k_wave_seams<false>, gRaw, dim3(kBlock), 0, s, R, n, (uint32_t)chunkLen, nChunks, tableSize - 1, hshift, starts, raw, gate);
+    hipLaunchKernelGGL(k_wave_bounds_scan, dim3(1), dim3(64), 0, s, raw, nChunks, numGran, bounds, gate);
 #define HJ_WV_LAUNCH(K32, CHK)                                                                                       \
     hipLaunchKernelGGL((k_build_wave<K32, CHK>), gMain, dim3(kWvThreads), kWvLdsBytes, s, R, n, sliceLen,           \
                        nChunks, starts, bounds, table, tableSize - 1, hshift, probeLen, idxBase, sc,                         \
-                       static_cast<DeferredEntry*>(queueBuf), dcounts, ctr)
+                       static_cast<DeferredEntry*>(queueBuf), dcounts, ctr, gate)
     if (sc.mask) { if (key32) HJ_WV_LAUNCH(true, true); else HJ_WV_LAUNCH(false, true); }
     else { if (key32) HJ_WV_LAUNCH(true, false); else HJ_WV_LAUNCH(false, false); }
 #undef HJ_WV_LAUNCH
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (evPhaseA && (e = hipEventRecord(evPhaseA, s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_wave_finalize_range, dim3(1), dim3(64), 0, s, ctr, tableSize);
-    hipLaunchKernelGGL(k_wave_fill_edges, dim3(2048), dim3(kBlock), 0, s, table, ctr, tableSize);
+    }
+    if (!(parts & 2)) return hipSuccess;
+    hipLaunchKernelGGL(k_wave_finalize_range, dim3(1), dim3(64), 0, s, ctr, tableSize, gate);
+    hipLaunchKernelGGL(k_wave_fill_edges, dim3(2048), dim3(kBlock), 0, s, table, ctr, tableSize, gate);
     hipLaunchKernelGGL(k_wave_deferred, dim3((nChunks + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, s,
                        static_cast<const DeferredEntry*>(queueBuf), dcounts, nChunks, sliceLen, table, tableSize - 1,
-                       hshift, probeLen, ctr);
+                       hshift, probeLen, ctr, gate);
     return hipGetLastError();
 }
 

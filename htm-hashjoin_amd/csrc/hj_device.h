@@ -53,7 +53,16 @@ struct Counters {
     unsigned long long foreign;      // tuples of the build / probe inputs that fail the shard check (ShardCheck)
     // Variant 3 (hj_build_wave.hip): the stretch of the table its wavefronts own and write whole, [ownLo, ownHiEx)
     unsigned long long ownLo, ownHiEx;
+    // Build kernel the device-side locality pre-round picked (hj_params.buildVariant 0): written by k_pick_variant,
+    // read through the Gate of every build kernel enqueued behind it, reported as hj_result.buildVariant
+    unsigned long long variant;
 };
+
+// Device-side choice between the build variants (hj_build_dev must stay asynchronous: no host read-back). The host
+// enqueues the kernels of EVERY candidate variant; each looks at the word the pre-round wrote and returns at once
+// unless it is the chosen one. word = nullptr: no gate (the variant was fixed on the host).
+struct Gate { const unsigned long long* word; unsigned long long want; };
+__device__ inline bool gate_closed(const Gate& g) { return g.word != nullptr && *g.word != g.want; }
 
 // A tuple that left its LDS window (variants 2 and 3): the slot it had reached and (index << 32 | key)
 struct DeferredEntry { uint64_t pos; uint64_t packed; };
@@ -61,14 +70,14 @@ struct DeferredEntry { uint64_t pos; uint64_t packed; };
 // ---- launch wrappers (defined in hj_kernels.hip) ---------------------------
 // Inputs come in two element formats: 8-byte DataGen tuples (key32 = false; value = key, payload bits must be 0)
 // or bare 32-bit keys (key32 = true; what the multi-GPU exchange delivers). Index of element i = idxBase + i.
-void launch_fill_empty(uint64_t* table, uint64_t nSlots, hipStream_t s);
+void launch_fill_empty(uint64_t* table, uint64_t nSlots, Gate gate, hipStream_t s);
 void launch_build_atomic_min(const void* R, bool key32, uint64_t n, uint64_t* table, uint64_t tableSize, uint32_t hshift,
-                             uint32_t probeLen, uint64_t idxBase, ShardCheck sc, Counters* ctr, hipStream_t s);
+                             uint32_t probeLen, uint64_t idxBase, ShardCheck sc, Counters* ctr, Gate gate, hipStream_t s);
 void launch_probe(const void* S, bool key32, uint64_t n, const uint64_t* table, uint64_t tableSize, uint32_t hshift,
                   uint32_t probeLen, ShardCheck sc, Counters* ctr, hipStream_t s);
 void launch_table_sums(const uint64_t* table, uint64_t tableSize, uint64_t halfSlots, Counters* ctr, hipStream_t s);
 // Marks the whole table valid (variant 1 clears and may touch all of it).
-void launch_set_full_range(uint64_t tableSize, Counters* ctr, hipStream_t s);
+void launch_set_full_range(uint64_t tableSize, Counters* ctr, Gate gate, hipStream_t s);
 // multi-GPU destination split (defined in hj_prj.hip: one order-preserving radix pass, tuples in, keys out);
 // destination = (key >> digitShift) & (nShards - 1)
 size_t shard_work_bytes(uint64_t n, uint32_t nShards);
@@ -84,16 +93,27 @@ bool   own_supported(uint64_t tableSize);
 // fitCount[0] = sampled tuples outside variant 2's window, [1] = tuples sampled, [2] = outside variant 3's ring
 hipError_t launch_sample_locality(const void* R, bool key32, uint64_t n, uint64_t tableSize, uint32_t hshift, uint32_t nSample,
                                   unsigned int* fitCount, hipStream_t s);
+// the pre-round's decision on the device: ctr->variant = 3 / 2 / 1 by the same thresholds the host applies
+// (sample_thresholds below); canOwn / canWave: which variants have their buffers
+void launch_pick_variant(const unsigned int* fitCount, bool canOwn, bool canWave, Counters* ctr, hipStream_t s);
+// variant worth taking for a sample (outside variant 2's window, tuples seen, outside variant 3's ring)
+__host__ __device__ inline uint32_t variant_for_sample(uint64_t outOwn, uint64_t seen, uint64_t outWave, bool canOwn, bool canWave)
+{
+    if (canWave && outWave * 128 <= seen) return 3;
+    if (canOwn && outOwn * 12 <= seen) return 2;
+    return 1;
+}
 hipError_t own_set_attributes();          // per device, at hj_create
 // phase A (LDS window) -> clear of unowned blocks -> phase B (deferred tuples).
 // Writes every table slot exactly once: no separate launch_fill_empty needed.
 hipError_t launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshift, uint64_t* table,
                             uint64_t tableSize, uint32_t probeLen, uint64_t idxBase, ShardCheck sc, int nCU, void* ownerBuf,
-                            void* queueBuf, unsigned long long* queueCount, Counters* ctr, hipEvent_t evPhaseA, hipStream_t s);
+                            void* queueBuf, unsigned long long* queueCount, Counters* ctr, Gate gate, int parts,
+                            hipEvent_t evPhaseA, hipStream_t s);   // parts: 1 = phase A (up to evPhaseA), 2 = the rest, 3 = both
 
 // phase B alone: finishes the queued tuples with global atomics (shared with variant 3)
 void launch_build_deferred(const void* queueBuf, const unsigned long long* queueCount, uint64_t* table, uint64_t tableSize,
-                           uint32_t hshift, uint32_t probeLen, Counters* ctr, hipStream_t s);
+                           uint32_t hshift, uint32_t probeLen, Counters* ctr, Gate gate, hipStream_t s);
 
 // ---- wavefront-private build (defined in hj_build_wave.hip) ------------------
 // geometry the locality sampler (k_sample_locality) needs to predict what k_build_wave would defer
@@ -108,7 +128,7 @@ size_t wave_queue_bytes(uint64_t n, int nCU);   // deferred queue: one slice per
 // slice per chunk (a wavefront's deferred tuples go to ITS slice: no atomics in the kernel).
 hipError_t launch_build_wave(const void* R, bool key32, uint64_t n, uint32_t hshift, uint64_t* table, uint64_t tableSize,
                              uint32_t probeLen, uint64_t idxBase, ShardCheck sc, int nCU, void* boundsBuf, void* queueBuf,
-                             Counters* ctr, hipEvent_t evPhaseA, hipStream_t s);
+                             Counters* ctr, Gate gate, int parts, hipEvent_t evPhaseA, hipStream_t s);
 
 // ---- PRJ (defined in hj_prj.hip) -------------------------------------------
 struct PrjPlan {
@@ -135,7 +155,8 @@ struct PrjBuffers {
 // evPartDone (may be null) is recorded between partitioning and join.
 hipError_t launch_prj(const PrjPlan& plan, const PrjBuffers& buf,
                       const uint64_t* R, uint64_t nR, const uint64_t* S, uint64_t nS, int nCU,
-                      Counters* ctr, hipEvent_t evPartDone, hipStream_t s);
+                      Counters* ctr, hipEvent_t evPartDone, hipEvent_t evScatter0, hipEvent_t evScatter1, hipStream_t s);
+// evScatter0/1 (may be null): recorded around the pass-1 scatter of R, PRJ's dominant kernel
 hipError_t prj_set_attributes();          // per device, at hj_create
 
 }  // namespace hj

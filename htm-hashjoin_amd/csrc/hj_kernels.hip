@@ -54,8 +54,9 @@ static inline unsigned grid_for(uint64_t items, unsigned perBlock)
 // ---------------------------------------------------------------------------
 // table clear: 16-byte stores of the empty pattern
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_fill_empty(uint64_t* __restrict__ table, uint64_t nSlots)
+__global__ void __launch_bounds__(kBlock) k_fill_empty(uint64_t* __restrict__ table, uint64_t nSlots, Gate gate)
 {
+    if (gate_closed(gate)) return;
     // table is hipMalloc'ed (256-B aligned); nSlots is even by construction
     ulonglong2* t2 = reinterpret_cast<ulonglong2*>(table);
     const uint64_t nv = nSlots >> 1;
@@ -65,9 +66,9 @@ __global__ void __launch_bounds__(kBlock) k_fill_empty(uint64_t* __restrict__ ta
     if (blockIdx.x == 0 && threadIdx.x == 0 && (nSlots & 1)) table[nSlots - 1] = kEmpty;
 }
 
-void launch_fill_empty(uint64_t* table, uint64_t nSlots, hipStream_t s)
+void launch_fill_empty(uint64_t* table, uint64_t nSlots, Gate gate, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_fill_empty, dim3(grid_for(nSlots / 2, kBlock * 4)), dim3(kBlock), 0, s, table, nSlots);
+    hipLaunchKernelGGL(k_fill_empty, dim3(grid_for(nSlots / 2, kBlock * 4)), dim3(kBlock), 0, s, table, nSlots, gate);
 }
 
 // ---------------------------------------------------------------------------
@@ -121,8 +122,10 @@ __device__ __forceinline__ void build_one(uint64_t t, uint64_t idx, uint64_t* __
 template <bool KEY32>
 __global__ void __launch_bounds__(kBlock)
 k_build_atomic_min(const void* __restrict__ Rv, uint64_t n, uint64_t* __restrict__ table,
-                   uint64_t mask, uint32_t hshift, uint32_t probeLen, uint64_t idxBase, ShardCheck sc, Counters* __restrict__ ctr)
+                   uint64_t mask, uint32_t hshift, uint32_t probeLen, uint64_t idxBase, ShardCheck sc, Counters* __restrict__ ctr,
+                   Gate gate)
 {
+    if (gate_closed(gate)) return;
     unsigned long long drops = 0, dropSum = 0, inSum = 0, bad = 0;
     if constexpr (KEY32) {
         const uint32_t* K = static_cast<const uint32_t*>(Rv);
@@ -153,14 +156,14 @@ k_build_atomic_min(const void* __restrict__ Rv, uint64_t n, uint64_t* __restrict
 }
 
 void launch_build_atomic_min(const void* R, bool key32, uint64_t n, uint64_t* table, uint64_t tableSize, uint32_t hshift,
-                             uint32_t probeLen, uint64_t idxBase, ShardCheck sc, Counters* ctr, hipStream_t s)
+                             uint32_t probeLen, uint64_t idxBase, ShardCheck sc, Counters* ctr, Gate gate, hipStream_t s)
 {
     if (key32)
         hipLaunchKernelGGL(k_build_atomic_min<true>, dim3(grid_for(n + 1, kBlock)), dim3(kBlock), 0, s,
-                           R, n, table, tableSize - 1, hshift, probeLen, idxBase, sc, ctr);
+                           R, n, table, tableSize - 1, hshift, probeLen, idxBase, sc, ctr, gate);
     else
         hipLaunchKernelGGL(k_build_atomic_min<false>, dim3(grid_for(n / 2 + 1, kBlock)), dim3(kBlock), 0, s,
-                           R, n, table, tableSize - 1, hshift, probeLen, idxBase, sc, ctr);
+                           R, n, table, tableSize - 1, hshift, probeLen, idxBase, sc, ctr, gate);
 }
 
 // ---------------------------------------------------------------------------
@@ -316,14 +319,15 @@ void launch_table_sums(const uint64_t* table, uint64_t tableSize, uint64_t halfS
                        table, tableSize, halfSlots, ctr);
 }
 
-__global__ void k_set_full_range(uint64_t tableSize, Counters* __restrict__ ctr)
+__global__ void k_set_full_range(uint64_t tableSize, Counters* __restrict__ ctr, Gate gate)
 {
+    if (gate_closed(gate)) return;
     if (threadIdx.x == 0 && blockIdx.x == 0) { ctr->validLo = 0; ctr->validHiEx = tableSize; }
 }
 
-void launch_set_full_range(uint64_t tableSize, Counters* ctr, hipStream_t s)
+void launch_set_full_range(uint64_t tableSize, Counters* ctr, Gate gate, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_set_full_range, dim3(1), dim3(64), 0, s, tableSize, ctr);
+    hipLaunchKernelGGL(k_set_full_range, dim3(1), dim3(64), 0, s, tableSize, ctr, gate);
 }
 
 }  // namespace hj

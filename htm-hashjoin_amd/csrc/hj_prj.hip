@@ -743,7 +743,8 @@ Work carve(const PrjPlan& pl, void* base)
 // One radix pass: in -> out, segments segIn[nSeg+1] -> segOut[nSeg*fan+1].
 // in32: the input already holds bare keys (pass 2); the output always does.
 hipError_t run_pass(const void* in, bool in32, uint32_t* out, uint64_t n, const uint32_t* segIn, uint32_t nSeg,
-                    uint32_t shift, uint32_t bits, uint32_t* segOut, const Work& w, hipStream_t s)
+                    uint32_t shift, uint32_t bits, uint32_t* segOut, const Work& w, hipStream_t s,
+                    hipEvent_t evScatter0 = nullptr, hipEvent_t evScatter1 = nullptr)
 {
     const uint32_t fan = 1u << bits;
     const PassLayout l = pass_layout(n, nSeg, fan);
@@ -762,32 +763,36 @@ hipError_t run_pass(const void* in, bool in32, uint32_t* out, uint64_t n, const 
     // instance choice measured at 2^30 (tools/prj_variants.sh, profiles/r01_prj_variants.txt): 512 threads x 16
     // elements, no register prefetch, <= 128 VGPRs (2 workgroups per CU); more, smaller workgroups and the
     // prefetching instance were slower or equal
+    if (evScatter0) (void)hipEventRecord(evScatter0, s);
     if (in32) hipLaunchKernelGGL((k_radix_scatter<true, true, 512, 4, false, 4>), dim3((unsigned)l.maxChunks), dim3(512), 0, s,
                                  in, static_cast<void*>(out), p, w.hist);
     else hipLaunchKernelGGL((k_radix_scatter<false, true, 512, 8, false, 4>), dim3((unsigned)l.maxChunks), dim3(512), 0, s,
                             in, static_cast<void*>(out), p, w.hist);
+    if (evScatter1) (void)hipEventRecord(evScatter1, s);
     return hipGetLastError();
 }
 
 hipError_t partition_relation(const PrjPlan& pl, const Work& w, const uint64_t* in, uint64_t n,
-                              uint32_t* tmp, uint32_t* out, uint32_t* finalOff, hipStream_t s)
+                              uint32_t* tmp, uint32_t* out, uint32_t* finalOff, hipStream_t s,
+                              hipEvent_t evS0 = nullptr, hipEvent_t evS1 = nullptr)
 {
     hipLaunchKernelGGL(k_init_seg, dim3(1), dim3(64), 0, s, w.seg0, (uint32_t)n);
-    if (pl.bits2 == 0) return run_pass(in, false, out, n, w.seg0, 1, 0, pl.bits1, finalOff, w, s);
-    const hipError_t e = run_pass(in, false, tmp, n, w.seg0, 1, 0, pl.bits1, w.seg1, w, s);             // pass 1, R = 0: tuples -> keys
+    if (pl.bits2 == 0) return run_pass(in, false, out, n, w.seg0, 1, 0, pl.bits1, finalOff, w, s, evS0, evS1);
+    const hipError_t e = run_pass(in, false, tmp, n, w.seg0, 1, 0, pl.bits1, w.seg1, w, s, evS0, evS1);   // pass 1, R = 0: tuples -> keys
     if (e != hipSuccess) return e;
     return run_pass(tmp, true, out, n, w.seg1, 1u << pl.bits1, pl.bits1, pl.bits2, finalOff, w, s);    // pass 2, R = bits1
 }
 }  // namespace
 
 hipError_t launch_prj(const PrjPlan& pl, const PrjBuffers& buf, const uint64_t* R, uint64_t nR,
-                      const uint64_t* S, uint64_t nS, int nCU, Counters* ctr, hipEvent_t evPartDone, hipStream_t s)
+                      const uint64_t* S, uint64_t nS, int nCU, Counters* ctr, hipEvent_t evPartDone, hipEvent_t evScatter0,
+                      hipEvent_t evScatter1, hipStream_t s)
 {
     const Work w = carve(pl, buf.work);
     uint32_t* const tmp = reinterpret_cast<uint32_t*>(buf.tmpA);
     uint32_t* const partR = reinterpret_cast<uint32_t*>(buf.partR);
     uint32_t* const partS = reinterpret_cast<uint32_t*>(buf.partS);
-    hipError_t e = partition_relation(pl, w, R, nR, tmp, partR, w.offR, s);
+    hipError_t e = partition_relation(pl, w, R, nR, tmp, partR, w.offR, s, evScatter0, evScatter1);
     if (e != hipSuccess) return e;
     if (S && (e = partition_relation(pl, w, S, nS, tmp, partS, w.offS, s)) != hipSuccess) return e;
     if (evPartDone && (e = hipEventRecord(evPartDone, s)) != hipSuccess) return e;

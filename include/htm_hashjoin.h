@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HJ_ABI_VERSION 2
+#define HJ_ABI_VERSION 3
 
 typedef enum {
     HJ_OK                  = 0,
@@ -115,6 +115,8 @@ typedef struct {
     uint32_t reserved0;
     uint64_t foreignTuples;   /* hj_set_shard_check: build + probe tuples whose
                                  destination is another shard (0 when the check is off) */
+    double   prjScatterPass1R_us; /* PRJ: device time of the pass-1 scatter of R alone (the
+                                 dominant kernel: 8 B read + 4 B written per tuple)      */
 } hj_result;
 
 typedef struct hj_ctx hj_ctx;
@@ -150,7 +152,9 @@ int hj_run(hj_ctx *ctx, const hj_params *params,
  * of NoCCHashBuild.hpp:24-31). Idempotent; grows only. */
 int hj_reserve(hj_ctx *ctx, const hj_params *params, uint64_t rSize, uint64_t sSize);
 /* HOT LOOP 1 (NoCCHashBuild.hpp:37-62 / AtomicHashBuild.hpp:37-67): clears the
- * table and inserts dR[0..rSize). Asynchronous on the context's stream.
+ * table and inserts dR[0..rSize). Asynchronous on the context's stream, also
+ * with buildVariant 0: the locality pre-round's decision is taken and acted on
+ * by the device (no read-back), hj_result.buildVariant reports it afterwards.
  * idxBase = global index of dR[0] (0 unless R is a shard of a larger input). */
 int hj_build_dev(hj_ctx *ctx, const uint64_t *dR, uint64_t rSize, uint64_t idxBase);
 /* HOT LOOP 2 (NoCCHashBuild.hpp:66-80): probes dS[0..sSize) against the table

@@ -36,11 +36,11 @@ def test_no_undeclared_exports():
 
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.hj_params) == 12 * 4
-    assert ctypes.sizeof(_lib.hj_result) == 12 * 8 + 2 * 4 + 7 * 8 + 4 * 8
+    assert ctypes.sizeof(_lib.hj_result) == 12 * 8 + 2 * 4 + 7 * 8 + 4 * 8 + 8
 
 
 def test_abi_version_and_strerror():
-    assert hj.lib.hj_abi_version() == 2
+    assert hj.lib.hj_abi_version() == 3
     assert b"no gfx950" in hj.lib.hj_strerror(_lib.HJ_ERR_NO_DEVICE)
     assert hj.lib.hj_strerror(0) == b"ok"
 

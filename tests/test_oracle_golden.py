@@ -154,3 +154,58 @@ def test_mt_port_agrees_on_unique_keys():
         mt = oracle.build_probe_mt(R, S, 4, 64, 4, atomic)
         for k in ("conflicts", "totalMatches", "inputSum", "outputSumNocc", "outputSumAtomic"):
             assert mt[k] == seq[k]
+
+
+# ---- Zipf generator: pinned by the reference's own gen_zipf -----------------------------------------------------------
+def _fnv1a64_u32(keys):
+    """FNV-1a-64 over the keys as little-endian uint32 (what oracle/zipf_ref_driver.c prints); vectorised per byte lane
+    is not possible for a running hash, so: plain loop over bytes in chunks, in C speed via int.from_bytes tricks is not
+    either -- the streams here are <= 2^21 keys = 8 MiB, a python loop over a bytes object is seconds."""
+    h = 1469598103934665603
+    for b in np.ascontiguousarray(keys, dtype="<u4").tobytes():
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _zipf_rows(golden_dir):
+    return _load(golden_dir, "zipf_ref.json")["rows"]
+
+
+def test_zipf_oracle_matches_the_references_gen_zipf(golden_dir):
+    """orc_generate_zipf (oracle/hj_oracle.c) against the reference's gen_zipf compiled from mc/src/genzipf.c
+    (tests/golden/zipf_ref.json, made by tests/golden/make_zipf_ref.py): every key of every stream (first keys, sum,
+    hash over all). Round 1 compared two restatements by the same hand with each other only."""
+    for row in _zipf_rows(golden_dir):
+        got = oracle.generate_zipf(row["stream_size"], row["alphabet_size"], row["theta"], row["seed"])
+        assert got[:32].tolist() == row["first"], row
+        assert int(got.sum()) == row["sum"], row
+        if row["stream_size"] <= 1 << 18:
+            assert _fnv1a64_u32(got) == row["fnv1a64"], row
+
+
+def test_zipf_product_generator_matches_the_references_gen_zipf(golden_dir):
+    """hj_generate_data("zipf") -- the product's own restatement of glibc rand() + gen_zipf -- for the seed-0 rows."""
+    import htm_hashjoin_amd as hj
+    n_checked = 0
+    for row in _zipf_rows(golden_dir):
+        if row["seed"] != 0:
+            continue
+        got = hj.generate_data("zipf", row["stream_size"], row["alphabet_size"], 16, zipf_theta=row["theta"])
+        assert got[:32].tolist() == row["first"], row
+        assert int(got.sum()) == row["sum"], row
+        if row["stream_size"] <= 1 << 18:
+            assert _fnv1a64_u32(got) == row["fnv1a64"], row
+        n_checked += 1
+    assert n_checked >= 5
+
+
+def test_zipf_reference_binary_still_agrees_with_the_fixture(golden_dir):
+    """Where the reference checkout is present the fixture is re-derived from the freshly built binary."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(oracle.REF_MCHASHJOINS), "genzipf_ref")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/genzipf_ref not built (no reference checkout here)")
+    for row in _zipf_rows(golden_dir)[:4]:
+        out = subprocess.run([exe, str(row["stream_size"]), str(row["alphabet_size"]), repr(row["theta"]), str(row["seed"]), "32"],
+                             capture_output=True, text=True, check=True).stdout
+        assert json.loads(out) == row
