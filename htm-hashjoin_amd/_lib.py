@@ -48,7 +48,8 @@ class hj_result(C.Structure):
         + [(n, C.c_double) for n in (
             "clear_us", "build_us", "probe_us", "partition_us", "join_us", "total_us", "h2d_us")]
         + [("buildDeferred", C.c_uint64), ("buildPhaseA_us", C.c_double), ("algoUsed", C.c_uint32),
-           ("reserved0", C.c_uint32), ("foreignTuples", C.c_uint64), ("prjScatterPass1R_us", C.c_double)]
+           ("reserved0", C.c_uint32), ("foreignTuples", C.c_uint64), ("prjScatterPass1R_us", C.c_double),
+           ("htmBuckets", C.c_uint64), ("htmOverflowBuckets", C.c_uint64), ("htmOverflowSum", C.c_uint64)]
     )
 
     def as_dict(self):
@@ -78,6 +79,7 @@ def _declare(lib):
         "hj_checksums_dev": ([vp], i32),
         "hj_fetch_result": ([vp, P(hj_result)], i32),
         "hj_export_table": ([vp, vp, u64], i32),
+        "hj_export_buckets": ([vp, vp, u64, vp, u64, P(u64)], i32),
         "hj_shard_histogram_dev": ([vp, vp, u64, u32, u32, vp], i32),
         "hj_shard_scatter_dev": ([vp, vp, u64, u32, u32, vp, vp], i32),
         "hj_build_keys_dev": ([vp, vp, u64, u32, u64], i32),

@@ -39,6 +39,13 @@ struct hj_ctx {
     unsigned int* fitCount = nullptr;           // device, 4 words (launch_sample_locality)
     unsigned int* hFit = nullptr;               // pinned
     void* boundsBuf = nullptr;                  // variant 3: per-chunk slot ranges (wave_bounds_bytes)
+    // bucketised table of --algo htm (hj_htm.hip): the table itself lives in `table` (4 slots per bucket)
+    bool htmBuilt = false;
+    uint32_t htmBuckets = 0;                    // numBuckets of the last htm build
+    uint64_t* htmConflicts = nullptr; size_t capHtmConflicts = 0;       // bytes
+    unsigned int* htmOvfCount = nullptr; uint32_t* htmOvfBase = nullptr; uint32_t* htmScan = nullptr; uint64_t capHtmBuckets = 0;
+    uint64_t* htmOverflow = nullptr; uint64_t capHtmOverflow = 0;       // overflow buckets (index 0 unused)
+    uint64_t htmOverflowUsed = 0;
     uint32_t variantUsed = 1;
     // counters
     Counters* dCtr = nullptr;
@@ -188,7 +195,8 @@ void hj_destroy(hj_ctx* c)
     hipSetDevice(c->device);
     if (c->stream || !c->ownStream) hipStreamSynchronize(c->stream);
     void* frees[] = {c->table, c->dCtr, c->tmpA, c->partR, c->partS, c->work, c->stageR, c->stageS,
-                     c->ownerBuf, c->queueBuf, c->queueCount, c->fitCount, c->boundsBuf, c->shard[0].work, c->shard[1].work,
+                     c->ownerBuf, c->queueBuf, c->queueCount, c->fitCount, c->boundsBuf, c->htmConflicts, c->htmOvfCount,
+                     c->htmOvfBase, c->htmScan, c->htmOverflow, c->shard[0].work, c->shard[1].work,
                      c->shard[2].work, c->shard[3].work};
     for (void* p : frees) if (p) hipFree(p);
     if (c->hCtr) hipHostFree(c->hCtr);
@@ -251,6 +259,32 @@ int hj_reserve(hj_ctx* c, const hj_params* params, uint64_t rSize, uint64_t sSiz
         // otherwise AUTO simply is the radix join, which has no such restriction
         if (!is_pow2(rSize) || rSize > (1ull << 31)) return HJ_OK;
     }
+    if (params->algo == HJ_ALGO_HTM) {
+        // the bucketised table (HTMHashBuild.hpp:61-72): nextpow2(rSize/3 + 1) buckets of 32 bytes = 4 slots each;
+        // any rSize (the hash is (key/3) & mask, not tied to rSize being a power of two)
+        if (rSize > (1ull << 31)) return fail(c, HJ_ERR_INVALID, "hj_reserve: rSize > 2^31 per device");
+        const uint64_t nb = htm_num_buckets(rSize);
+        int rc = grow(c, c->table, c->tableCapSlots, 4 * nb + kTableSlack);
+        if (rc) return rc;
+        const size_t qb = wave_queue_bytes(rSize, c->nCU), cb = wave_conflict_bytes(rSize, c->nCU);
+        if (qb > c->capQueue) {
+            if (c->queueBuf) { HJ_HIP(c, hipFree(c->queueBuf)); c->queueBuf = nullptr; c->capQueue = 0; }
+            HJ_HIP(c, hipMalloc(&c->queueBuf, qb)); c->capQueue = qb;
+        }
+        if (cb > c->capHtmConflicts) {
+            if (c->htmConflicts) { HJ_HIP(c, hipFree(c->htmConflicts)); c->htmConflicts = nullptr; c->capHtmConflicts = 0; }
+            HJ_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->htmConflicts), cb)); c->capHtmConflicts = cb;
+        }
+        if (nb > c->capHtmBuckets) {
+            for (void* p : {(void*)c->htmOvfCount, (void*)c->htmOvfBase, (void*)c->htmScan}) if (p) HJ_HIP(c, hipFree(p));
+            c->htmOvfCount = nullptr; c->htmOvfBase = nullptr; c->htmScan = nullptr; c->capHtmBuckets = 0;
+            HJ_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->htmOvfCount), nb * sizeof(unsigned int)));
+            HJ_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->htmOvfBase), nb * sizeof(uint32_t)));
+            HJ_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->htmScan), scan_workspace_words(nb) * sizeof(uint32_t)));
+            c->capHtmBuckets = nb;
+        }
+        return HJ_OK;
+    }
     if (!is_pow2(rSize)) return fail(c, HJ_ERR_INVALID, "hj_reserve: rSize must be a power of two (DataGen.hpp:28, NoCCHashBuild.hpp:36)");
     if (rSize > (1ull << 31)) return fail(c, HJ_ERR_INVALID, "hj_reserve: rSize > 2^31 per device");
     int rc = grow(c, c->table, c->tableCapSlots, 2 * rSize + kTableSlack);
@@ -300,7 +334,7 @@ static int build_common(hj_ctx* c, const void* d, bool key32, uint64_t n, uint32
     HJ_HIP(c, hipSetDevice(c->device));
     c->rSize = n; c->sSize = 0; c->tableSize = tableSize; c->hshift = hshift;
     for (bool& b : c->evSet) b = false;
-    c->prjRan = false;
+    c->prjRan = false; c->htmBuilt = false;
     HJ_HIP(c, hipMemsetAsync(c->dCtr, 0, sizeof(Counters), c->stream));
     int rc;
     if ((rc = record(c, EV_CLEAR0))) return rc;
@@ -362,10 +396,68 @@ static int build_common(hj_ctx* c, const void* d, bool key32, uint64_t n, uint32
     return HJ_OK;
 }
 
+// --algo htm: the bucketised table (hj_htm.hip). Not asynchronous: the number of conflicts is read back once, to size
+// the overflow area (the reference, too, builds its chains in a serial phase after the parallel build, :231-279).
+static int build_htm(hj_ctx* c, const uint64_t* dR, uint64_t rSize, uint64_t idxBase)
+{
+    HJ_HIP(c, hipSetDevice(c->device));
+    const uint32_t nb = htm_num_buckets(rSize);
+    const uint64_t slots = 4ull * nb;
+    if (slots + kTableSlack > c->tableCapSlots || nb > c->capHtmBuckets || c->capQueue < wave_queue_bytes(rSize, c->nCU) ||
+        c->capHtmConflicts < wave_conflict_bytes(rSize, c->nCU))
+        return fail(c, HJ_ERR_STATE, "hj_build_dev: hj_reserve() not called for this rSize (htm)");
+    if (idxBase + rSize > 0xFFFFFFFFull) return fail(c, HJ_ERR_INVALID, "hj_build_dev: index range exceeds 2^32 - 1");
+    c->rSize = rSize; c->sSize = 0; c->tableSize = slots; c->hshift = 0; c->htmBuckets = nb;
+    for (bool& b : c->evSet) b = false;
+    c->prjRan = false; c->built = false; c->htmBuilt = false;
+    HJ_HIP(c, hipMemsetAsync(c->dCtr, 0, sizeof(Counters), c->stream));
+    int rc;
+    if ((rc = record(c, EV_CLEAR0))) return rc;
+    // locality pre-round on the key order (bucket = key / 3 keeps it): rings if they will do, else global atomics
+    uint32_t variant = c->params.buildVariant == 1 ? 1 : 3;
+    if (!wave_supported(slots)) variant = 1;
+    if (variant == 3 && c->params.buildVariant == 0 &&
+        (rc = sample_variant(c, dR, false, rSize, slots, 0, false, true, &variant))) return rc;
+    c->variantUsed = variant; c->algoUsed = HJ_ALGO_HTM;
+    const WaveSlices sl = wave_conflict_layout(rSize, c->nCU, c->boundsBuf);
+    if (variant == 3) {
+        if ((rc = record(c, EV_BUILD0))) return rc;
+        HJ_HIP(c, launch_build_wave(dR, false, rSize, 0, c->table, slots, 3, idxBase, ShardCheck{0, 0, 0, 0}, c->nCU, c->boundsBuf,
+                                    c->queueBuf, c->dCtr, Gate{nullptr, 0}, 3, c->ev[EV_BUILD_A], c->stream, c->htmConflicts));
+        c->evSet[EV_BUILD_A] = true;
+    } else {
+        launch_fill_empty(c->table, slots + kTableSlack, Gate{nullptr, 0}, c->stream);
+        launch_set_full_range(slots, c->dCtr, Gate{nullptr, 0}, c->stream);
+        HJ_HIP(c, hipGetLastError());
+        if ((rc = record(c, EV_BUILD0))) return rc;
+        HJ_HIP(c, launch_htm_build_global(dR, rSize, sl.sliceLen, sl.nChunks, c->table, slots, idxBase, c->htmConflicts,
+                                          const_cast<uint32_t*>(sl.counts), c->dCtr, c->stream));
+    }
+    // chains: count per bucket, reserve overflow buckets by one scan, fill them in index order, link
+    HJ_HIP(c, launch_htm_count(c->htmConflicts, sl.counts, sl.nChunks, sl.sliceLen, nb, c->htmOvfCount, c->htmOvfBase, c->stream));
+    HJ_HIP(c, launch_exclusive_scan_u32(c->htmOvfBase, nb, c->htmScan, c->stream));
+    HJ_HIP(c, hipMemcpyAsync(c->hCtr, c->dCtr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+    HJ_HIP(c, hipStreamSynchronize(c->stream));
+    const uint64_t conflicts = c->hCtr->conflicts;              // >= overflow buckets needed
+    if (conflicts + 1 > c->capHtmOverflow) {
+        if (c->htmOverflow) { HJ_HIP(c, hipFree(c->htmOverflow)); c->htmOverflow = nullptr; c->capHtmOverflow = 0; }
+        const uint64_t cap = conflicts + conflicts / 8 + 64;
+        HJ_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->htmOverflow), (cap + 1) * 4 * sizeof(uint64_t)));
+        c->capHtmOverflow = cap + 1;
+    }
+    c->htmOverflowUsed = conflicts;
+    HJ_HIP(c, launch_htm_chains(c->htmConflicts, sl.counts, sl.nChunks, sl.sliceLen, c->table, nb, c->htmOvfCount, c->htmOvfBase,
+                                c->htmOverflow, conflicts, c->dCtr, c->stream));
+    if ((rc = record(c, EV_BUILD1))) return rc;
+    c->built = true; c->htmBuilt = true;
+    return HJ_OK;
+}
+
 int hj_build_dev(hj_ctx* c, const uint64_t* dR, uint64_t rSize, uint64_t idxBase)
 {
     if (!c || !dR) return HJ_ERR_INVALID;
     if (c->params.algo == HJ_ALGO_PRJ) return fail(c, HJ_ERR_STATE, "hj_build_dev: context is reserved for PRJ");
+    if (c->params.algo == HJ_ALGO_HTM) return rSize ? build_htm(c, dR, rSize, idxBase) : HJ_ERR_INVALID;
     if (!is_pow2(rSize) || 2 * rSize + kTableSlack > c->tableCapSlots)
         return fail(c, HJ_ERR_STATE, "hj_build_dev: hj_reserve() not called for this rSize");
     // indices stay below 2^32 - 1: (index << 32 | key) of index = key = 0xFFFFFFFF would be the empty pattern
@@ -376,7 +468,8 @@ int hj_build_dev(hj_ctx* c, const uint64_t* dR, uint64_t rSize, uint64_t idxBase
 int hj_build_keys_dev(hj_ctx* c, const uint32_t* dKeys, uint64_t n, uint32_t homeShift, uint64_t tableSize)
 {
     if (!c || (!dKeys && n)) return HJ_ERR_INVALID;
-    if (c->params.algo == HJ_ALGO_PRJ) return fail(c, HJ_ERR_STATE, "hj_build_keys_dev: context is reserved for PRJ");
+    if (c->params.algo == HJ_ALGO_PRJ || c->params.algo == HJ_ALGO_HTM)
+        return fail(c, HJ_ERR_STATE, "hj_build_keys_dev: context is reserved for PRJ / htm");
     if (homeShift > 6) return fail(c, HJ_ERR_INVALID, "hj_build_keys_dev: homeShift must be in [0,6]");
     if (!is_pow2(tableSize) || tableSize + kTableSlack > c->tableCapSlots)
         return fail(c, HJ_ERR_STATE, "hj_build_keys_dev: hj_reserve() not called for this table size");
@@ -391,7 +484,8 @@ int hj_probe_dev(hj_ctx* c, const uint64_t* dS, uint64_t sSize)
     HJ_HIP(c, hipSetDevice(c->device));
     int rc;
     if ((rc = record(c, EV_PROBE0))) return rc;
-    if (sSize) launch_probe(dS, false, sSize, c->table, c->tableSize, c->hshift, probe_len(c->params), c->sc, c->dCtr, c->stream);
+    if (sSize && c->htmBuilt) launch_htm_probe(dS, sSize, c->table, c->htmBuckets, c->htmOverflow, c->dCtr, c->stream);
+    else if (sSize) launch_probe(dS, false, sSize, c->table, c->tableSize, c->hshift, probe_len(c->params), c->sc, c->dCtr, c->stream);
     if ((rc = record(c, EV_PROBE1))) return rc;
     HJ_HIP(c, hipGetLastError());
     c->sSize += sSize;
@@ -401,7 +495,7 @@ int hj_probe_dev(hj_ctx* c, const uint64_t* dS, uint64_t sSize)
 int hj_probe_keys_dev(hj_ctx* c, const uint32_t* dKeys, uint64_t n)
 {
     if (!c || (!dKeys && n)) return HJ_ERR_INVALID;
-    if (!c->built) return fail(c, HJ_ERR_STATE, "hj_probe_keys_dev: no table (build first)");
+    if (!c->built || c->htmBuilt) return fail(c, HJ_ERR_STATE, "hj_probe_keys_dev: no open-addressing table (build first)");
     HJ_HIP(c, hipSetDevice(c->device));
     int rc;
     if ((rc = record(c, EV_PROBE0))) return rc;
@@ -482,6 +576,12 @@ int hj_checksums_dev(hj_ctx* c)
     HJ_HIP(c, hipSetDevice(c->device));
     // zero the two sums so the call is idempotent
     HJ_HIP(c, hipMemsetAsync(&c->dCtr->tableSumHalf, 0, 2 * sizeof(unsigned long long), c->stream));
+    if (c->htmBuilt) {
+        HJ_HIP(c, hipMemsetAsync(&c->dCtr->htmOverflowSum, 0, sizeof(unsigned long long), c->stream));
+        launch_htm_sums(c->table, c->htmBuckets, c->htmOverflow, c->dCtr, c->stream);
+        HJ_HIP(c, hipGetLastError());
+        return HJ_OK;
+    }
     launch_table_sums(c->table, c->tableSize, c->tableSize / 2, c->dCtr, c->stream);
     HJ_HIP(c, hipGetLastError());
     return HJ_OK;
@@ -513,6 +613,12 @@ int hj_fetch_result(hj_ctx* c, hj_result* out)
         out->tableSumHalf = k.tableSumHalf;
         out->tableSumFull = k.tableSumFull;
         out->outputSum = (c->params.algo == HJ_ALGO_NOCC ? k.tableSumHalf : k.tableSumFull) + k.conflictSum;
+        if (c->htmBuilt) {
+            // every conflict sits in an overflow bucket of its own bucket's chain: tuples in buckets + tuples in
+            // chains = input (HTMHashBuild.hpp:452 adds conflictSum on top of the chains, counting them twice)
+            out->htmBuckets = c->htmBuckets; out->htmOverflowBuckets = k.htmOverflowBuckets; out->htmOverflowSum = k.htmOverflowSum;
+            out->outputSum = k.tableSumFull + k.htmOverflowSum;
+        }
         out->buildVariant = c->variantUsed ? c->variantUsed : (uint32_t)k.variant;   // 0: the device chose
         out->buildDeferred = k.deferred;
         out->buildPhaseA_us = elapsed_us(c, EV_BUILD0, EV_BUILD_A);
@@ -533,7 +639,7 @@ int hj_fetch_result(hj_ctx* c, hj_result* out)
 int hj_export_table(hj_ctx* c, uint64_t* host_table, uint64_t tableSize)
 {
     if (!c || !host_table) return HJ_ERR_INVALID;
-    if (!c->built || tableSize != c->tableSize) return fail(c, HJ_ERR_STATE, "hj_export_table: no table of that size");
+    if (!c->built || c->htmBuilt || tableSize != c->tableSize) return fail(c, HJ_ERR_STATE, "hj_export_table: no open-addressing table of that size");
     HJ_HIP(c, hipSetDevice(c->device));
     HJ_HIP(c, hipMemcpyAsync(host_table, c->table, tableSize * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HJ_HIP(c, hipStreamSynchronize(c->stream));
@@ -544,6 +650,38 @@ int hj_export_table(hj_ctx* c, uint64_t* host_table, uint64_t tableSize)
     const uint64_t lo = k.validLo, hi = k.validHiEx + 512 < tableSize ? k.validHiEx + 512 : tableSize;
     for (uint64_t i = 0; i < tableSize; ++i)
         host_table[i] = (i < lo || i >= hi || host_table[i] == kEmpty) ? 0 : (uint32_t)host_table[i];
+    return HJ_OK;
+}
+
+int hj_export_buckets(hj_ctx* c, void* host_buckets, uint64_t numBuckets, void* host_overflows, uint64_t overflowCap,
+                      uint64_t* nOverflow)
+{
+    if (!c || !host_buckets) return HJ_ERR_INVALID;
+    if (!c->htmBuilt || numBuckets != c->htmBuckets) return fail(c, HJ_ERR_STATE, "hj_export_buckets: no htm table of that many buckets");
+    HJ_HIP(c, hipSetDevice(c->device));
+    HJ_HIP(c, hipMemcpyAsync(c->hCtr, c->dCtr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+    HJ_HIP(c, hipStreamSynchronize(c->stream));
+    const uint64_t used = c->hCtr->htmOverflowBuckets;
+    if (nOverflow) *nOverflow = used;
+    if (used && (!host_overflows || overflowCap < used + 1)) return fail(c, HJ_ERR_INVALID, "hj_export_buckets: overflow buffer too small");
+    // device format (index << 32 | key, all ones = empty, slot 3 = next << 32 | count) -> struct Bucket {tuples[3], count, nextIndex}
+    auto convert = [](uint64_t* b, uint64_t n) {
+        for (uint64_t i = 0; i < n; ++i) {
+            uint64_t* p = b + 4 * i;
+            const uint32_t count = (uint32_t)p[3], next = (uint32_t)(p[3] >> 32);
+            for (int j = 0; j < 3; ++j) p[j] = (p[j] == kEmpty) ? 0 : (uint32_t)p[j];
+            p[3] = (uint64_t)count | ((uint64_t)next << 32);     // little-endian {uint32 count; uint32 nextIndex}
+        }
+    };
+    HJ_HIP(c, hipMemcpy(host_buckets, c->table, numBuckets * 32, hipMemcpyDeviceToHost));
+    convert(static_cast<uint64_t*>(host_buckets), numBuckets);
+    if (host_overflows) {
+        memset(host_overflows, 0, 32);                           // index 0 is unused (as in the reference)
+        if (used) {
+            HJ_HIP(c, hipMemcpy(static_cast<char*>(host_overflows) + 32, c->htmOverflow + 4, used * 32, hipMemcpyDeviceToHost));
+            convert(static_cast<uint64_t*>(host_overflows) + 4, used);
+        }
+    }
     return HJ_OK;
 }
 

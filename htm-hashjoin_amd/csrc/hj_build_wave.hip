@@ -111,7 +111,7 @@ constexpr uint32_t kWvLook = 512;
 #define HJ_WV_OVERLAP 64
 #endif
 constexpr uint32_t kWvOverlap = HJ_WV_OVERLAP;
-template <bool KEY32>
+template <bool KEY32, bool HTM>
 __global__ void __launch_bounds__(kBlock)
 k_wave_seams(const void* __restrict__ Rv, uint64_t n, uint32_t chunkLen, uint32_t nChunks, uint64_t mask,
              uint32_t hshift, uint32_t* __restrict__ starts, uint32_t* __restrict__ raw, Gate gate)
@@ -131,7 +131,7 @@ k_wave_seams(const void* __restrict__ Rv, uint64_t n, uint32_t chunkLen, uint32_
         h[k] = kNone;
         if (i < n) {
             const uint64_t t = R[i];
-            if ((t >> 32) == 0 && t != 0) h[k] = (uint32_t)home_slot((uint32_t)t, hshift, mask);
+            if ((t >> 32) == 0 && t != 0) h[k] = home32<HTM>((uint32_t)t, hshift, (uint32_t)mask);
         }
     }
     const uint32_t m = wave_umin(h[0]);
@@ -184,12 +184,13 @@ k_wave_bounds_scan(const uint32_t* __restrict__ raw, uint32_t nChunks, uint32_t 
 }
 
 // ---- the build ------------------------------------------------------------------------------------------------
-template <bool KEY32, bool CHECK>
+template <bool KEY32, bool CHECK, bool HTM>
 __global__ void __launch_bounds__(kWvThreads, 4)
 k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_t nChunks, const uint32_t* __restrict__ starts,
              const uint32_t* __restrict__ bounds, uint64_t* __restrict__ table, uint64_t mask, uint32_t hshift,
              uint32_t probeLen, uint64_t idxBase, ShardCheck sc, DeferredEntry* __restrict__ queue,
-             uint32_t* __restrict__ dcounts, Counters* __restrict__ ctr, Gate gate)
+             uint32_t* __restrict__ dcounts, Counters* __restrict__ ctr, Gate gate, uint64_t* __restrict__ htmConflicts,
+             uint32_t* __restrict__ ccounts)
 {
     if (gate_closed(gate)) return;
     extern __shared__ __align__(16) uint64_t lds[];
@@ -227,6 +228,9 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
     uint32_t drops = 0, bad = 0, foreign = 0;
     uint32_t dCount = 0;                         // tuples deferred so far (wave-uniform)
     DeferredEntry* const myDeferred = queue + (uint64_t)c * sliceLen;      // <= clen + kWvOverlap <= sliceLen entries
+    uint32_t cCount = 0;                         // HTM: conflicts recorded so far (wave-uniform)
+    uint64_t* const myConflicts = HTM ? htmConflicts + (uint64_t)c * sliceLen : nullptr;
+    (void)cCount; (void)myConflicts;
     uint32_t usedLo = kNone, usedHi1 = 0;        // 512-slot blocks this lane deferred into (Counters::usedLoInv / usedHi1)
 
     // the ring's tail up to granule `target` leaves for HBM (empties included) and its LDS copy is reset
@@ -250,7 +254,7 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
     // deferred; returns "not finished" with the entry's next state in place.
     auto round_body = [&](uint32_t& pos, uint32_t& mlo, uint32_t& mhi, const bool has) -> bool {
         const uint32_t key = mlo;
-        uint32_t budget = probeLen - ((pos - ((key >> hshift) & mask32)) & mask32);
+        uint32_t budget = probeLen - ((pos - home32<HTM>(key, hshift, mask32)) & mask32);
         const bool ownOk = in_ring(pos);
         const bool drop0 = has & (budget == 0);
         const bool toDefer = has & !drop0 & !ownOk;
@@ -277,6 +281,13 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
         mlo = disp ? (uint32_t)old : mlo; mhi = disp ? (uint32_t)(old >> 32) : mhi;
         const bool dropped = drop0 | drop1;
         drops += dropped ? 1u : 0u; dropSum += dropped ? (unsigned long long)key : 0ull;
+        if constexpr (HTM) {       // the bucket is full: the tuple is one of the reference's conflicts (HTMHashBuild.hpp:181-183)
+            const unsigned long long cm = __ballot(dropped);
+            if (cm) {
+                if (dropped) myConflicts[cCount + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull))] = mine;
+                cCount += (uint32_t)__popcll(cm);
+            }
+        }
         // deferred tuples go to this wavefront's OWN slice of the deferred queue, [cb, cb + clen): a tuple leaves at
         // most once, so the slice cannot overflow, and no atomic is needed to place it (a returning global atomic
         // per round with a straggler stalled the wavefront for microseconds)
@@ -365,7 +376,7 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
                 const uint32_t o = tb + lane + 64 * j;
                 const bool in = FULL || (o < clen);                               // counted here
                 const bool okKey = (khi[j] == 0) & (klo[j] != 0);
-                home[j] = (klo[j] >> hshift) & mask32;
+                home[j] = home32<HTM>(klo[j], hshift, mask32);
                 // inserted here: my tuples, except head-zone stragglers of the previous range; plus the next chunk's
                 // stragglers of MY range in the overlap zone
                 const bool mineHere = FULL || (o < clen ? !((o < kWvOverlap) & (home[j] < loSlot))
@@ -447,6 +458,7 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
         if (c == 0) ctr->ownLo = (unsigned long long)loG << kGranShift;
         if (lastChunk) ctr->ownHiEx = (unsigned long long)winLoG << kGranShift;
         dcounts[c] = dCount;
+        if constexpr (HTM) ccounts[c] = cCount;
     }
 
     // counters: one atomic per wavefront
@@ -479,10 +491,11 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
 // Phase B for the sliced deferred queue: chunk c's entries are queue[c * chunkLen .. + dcounts[c]). Same walk as
 // k_build_deferred (hj_build_own.hip): the probe walk of every deferred tuple finished with global atomics. One
 // wavefront per chunk slice at a time, slices dealt round-robin.
+template <bool HTM>
 __global__ void __launch_bounds__(kBlock)
 k_wave_deferred(const DeferredEntry* __restrict__ queue, const uint32_t* __restrict__ dcounts, uint32_t nChunks,
                 uint32_t chunkLen, uint64_t* __restrict__ table, uint64_t mask, uint32_t hshift, uint32_t probeLen,
-                Counters* __restrict__ ctr, Gate gate)
+                Counters* __restrict__ ctr, Gate gate, uint64_t* __restrict__ htmConflicts, uint32_t* __restrict__ ccounts)
 {
     if (gate_closed(gate)) return;
     const uint32_t lane = threadIdx.x & 63;
@@ -491,26 +504,36 @@ k_wave_deferred(const DeferredEntry* __restrict__ queue, const uint32_t* __restr
     for (uint32_t c = w0; c < nChunks; c += nWaves) {
         const uint32_t cnt = dcounts[c];
         const DeferredEntry* q = queue + (uint64_t)c * chunkLen;
-        for (uint32_t i = lane; i < cnt; i += 64) {
-            uint64_t mine = q[i].packed;
-            uint64_t pos = q[i].pos;
-            const uint64_t home0 = home_slot((uint32_t)mine, hshift, mask);
+        uint32_t cCount = HTM ? ccounts[c] : 0u;                       // this slice's conflicts so far (one wavefront per slice)
+        for (uint32_t i0 = 0; i0 < cnt; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const bool has = i < cnt;
+            uint64_t mine = has ? q[i].packed : 0ull;
+            uint64_t pos = has ? q[i].pos : 0ull;
+            const uint64_t home0 = home32<HTM>((uint32_t)mine, hshift, (uint32_t)mask);
             uint32_t budget = probeLen - (uint32_t)((pos - home0) & mask);
-            for (;;) {
-                if (budget == 0) { drops += 1; dropSum += (uint32_t)mine; break; }
+            bool dropped = false;
+            for (; has;) {
+                if (budget == 0) { drops += 1; dropSum += (uint32_t)mine; dropped = true; break; }
                 const unsigned long long old =
                     atomicMin(reinterpret_cast<unsigned long long*>(table + pos), (unsigned long long)mine);
                 if (old == kEmpty || old == mine) break;
                 if (old > mine) {
                     mine = old;
-                    const uint64_t home = home_slot((uint32_t)old, hshift, mask);
+                    const uint64_t home = home32<HTM>((uint32_t)old, hshift, (uint32_t)mask);
                     budget = probeLen - ((uint32_t)((pos - home) & mask) + 1);
                 } else {
                     budget -= 1;
                 }
                 pos = (pos + 1) & mask;
             }
+            if constexpr (HTM) {
+                const unsigned long long cm = __ballot(dropped);
+                if (dropped) htmConflicts[(uint64_t)c * chunkLen + cCount + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull))] = mine;
+                cCount += (uint32_t)__popcll(cm);
+            }
         }
+        if (HTM && lane == 0) ccounts[c] = cCount;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -561,7 +584,7 @@ k_wave_fill_edges(uint64_t* __restrict__ table, const Counters* __restrict__ ctr
 size_t wave_lds_bytes() { return kWvLdsBytes; }
 bool wave_supported(uint64_t tableSize) { return tableSize >= (uint64_t)kWvWin; }
 uint32_t wave_max_chunks(int nCU) { return 16u * (uint32_t)nCU; }
-size_t wave_bounds_bytes(int nCU) { return (4 * (size_t)wave_max_chunks(nCU) + 4) * sizeof(uint32_t); }   // raw, bounds (+1), starts (+1), dcounts
+size_t wave_bounds_bytes(int nCU) { return (5 * (size_t)wave_max_chunks(nCU) + 4) * sizeof(uint32_t); }   // raw, bounds (+1), starts (+1), dcounts, ccounts
 static uint64_t wave_chunk_len(uint64_t n, int nCU)
 {
     // one chunk per resident wavefront: a single round of workgroups, no tail
@@ -577,10 +600,21 @@ size_t wave_queue_bytes(uint64_t n, int nCU)
     return (size_t)(((n + chunkLen - 1) / chunkLen) * wave_slice_len(chunkLen) + 64) * sizeof(DeferredEntry);
 }
 
+WaveSlices wave_conflict_layout(uint64_t n, int nCU, void* boundsBuf)
+{
+    const uint32_t maxChunks = wave_max_chunks(nCU);
+    const uint64_t chunkLen = wave_chunk_len(n, nCU);
+    return WaveSlices{(uint32_t)((n + chunkLen - 1) / chunkLen), (uint32_t)wave_slice_len(chunkLen),
+                      static_cast<const uint32_t*>(boundsBuf) + 4 * (size_t)maxChunks + 2};
+}
+size_t wave_conflict_bytes(uint64_t n, int nCU) { return wave_queue_bytes(n, nCU) / sizeof(DeferredEntry) * sizeof(uint64_t); }
+
 hipError_t launch_build_wave(const void* R, bool key32, uint64_t n, uint32_t hshift, uint64_t* table, uint64_t tableSize,
                              uint32_t probeLen, uint64_t idxBase, ShardCheck sc, int nCU, void* boundsBuf, void* queueBuf,
-                             Counters* ctr, Gate gate, int parts, hipEvent_t evPhaseA, hipStream_t s)
+                             Counters* ctr, Gate gate, int parts, hipEvent_t evPhaseA, hipStream_t s, uint64_t* htmConflicts)
 {
+    const bool htm = htmConflicts != nullptr;
+    if (htm && (key32 || probeLen != 3 || sc.mask)) return hipErrorInvalidValue;
     const uint32_t maxChunks = wave_max_chunks(nCU);
     const uint64_t chunkLen = wave_chunk_len(n, nCU);
     static_assert(kWvTile * 4 > (int)(kWvLook + kWvOverlap), "a seam may move by less than the shortest chunk");
@@ -590,19 +624,22 @@ hipError_t launch_build_wave(const void* R, bool key32, uint64_t n, uint32_t hsh
     uint32_t* const bounds = raw + maxChunks;                 // nChunks + 1 entries
     uint32_t* const starts = bounds + maxChunks + 1;          // nChunks + 1 entries
     uint32_t* const dcounts = starts + maxChunks + 1;
+    uint32_t* const ccounts = dcounts + maxChunks;            // == wave_conflict_layout(...).counts
     const uint32_t numGran = (uint32_t)(tableSize >> kGranShift);
     hipError_t e;
     const dim3 gRaw((nChunks + 1 + kBlock / 64 - 1) / (kBlock / 64)), gMain((nChunks + kWvWaves - 1) / kWvWaves);
     if (parts & 1) {
-    if (key32) hipLaunchKernelGGL(k_wave_seams<true>, gRaw, dim3(kBlock), 0, s, R, n, (uint32_t)chunkLen, nChunks, tableSize - 1, hshift, starts, raw, gate);
-    else hipLaunchKernelGGL(k_wave_seams<false>, gRaw, dim3(kBlock), 0, s, R, n, (uint32_t)chunkLen, nChunks, tableSize - 1, hshift, starts, raw, gate);
+    if (htm) hipLaunchKernelGGL((k_wave_seams<false, true>), gRaw, dim3(kBlock), 0, s, R, n, (uint32_t)chunkLen, nChunks, tableSize - 1, hshift, starts, raw, gate);
+    else if (key32) hipLaunchKernelGGL((k_wave_seams<true, false>), gRaw, dim3(kBlock), 0, s, R, n, (uint32_t)chunkLen, nChunks, tableSize - 1, hshift, starts, raw, gate);
+    else hipLaunchKernelGGL((k_wave_seams<false, false>), gRaw, dim3(kBlock), 0, s, R, n, (uint32_t)chunkLen, nChunks, tableSize - 1, hshift, starts, raw, gate);
     hipLaunchKernelGGL(k_wave_bounds_scan, dim3(1), dim3(64), 0, s, raw, nChunks, numGran, bounds, gate);
-#define HJ_WV_LAUNCH(K32, CHK)                                                                                       \
-    hipLaunchKernelGGL((k_build_wave<K32, CHK>), gMain, dim3(kWvThreads), kWvLdsBytes, s, R, n, sliceLen,           \
+#define HJ_WV_LAUNCH(K32, CHK, HTM)                                                                                  \
+    hipLaunchKernelGGL((k_build_wave<K32, CHK, HTM>), gMain, dim3(kWvThreads), kWvLdsBytes, s, R, n, sliceLen,      \
                        nChunks, starts, bounds, table, tableSize - 1, hshift, probeLen, idxBase, sc,                         \
-                       static_cast<DeferredEntry*>(queueBuf), dcounts, ctr, gate)
-    if (sc.mask) { if (key32) HJ_WV_LAUNCH(true, true); else HJ_WV_LAUNCH(false, true); }
-    else { if (key32) HJ_WV_LAUNCH(true, false); else HJ_WV_LAUNCH(false, false); }
+                       static_cast<DeferredEntry*>(queueBuf), dcounts, ctr, gate, htmConflicts, ccounts)
+    if (htm) HJ_WV_LAUNCH(false, false, true);
+    else if (sc.mask) { if (key32) HJ_WV_LAUNCH(true, true, false); else HJ_WV_LAUNCH(false, true, false); }
+    else { if (key32) HJ_WV_LAUNCH(true, false, false); else HJ_WV_LAUNCH(false, false, false); }
 #undef HJ_WV_LAUNCH
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (evPhaseA && (e = hipEventRecord(evPhaseA, s)) != hipSuccess) return e;
@@ -610,9 +647,11 @@ hipError_t launch_build_wave(const void* R, bool key32, uint64_t n, uint32_t hsh
     if (!(parts & 2)) return hipSuccess;
     hipLaunchKernelGGL(k_wave_finalize_range, dim3(1), dim3(64), 0, s, ctr, tableSize, gate);
     hipLaunchKernelGGL(k_wave_fill_edges, dim3(2048), dim3(kBlock), 0, s, table, ctr, tableSize, gate);
-    hipLaunchKernelGGL(k_wave_deferred, dim3((nChunks + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, s,
-                       static_cast<const DeferredEntry*>(queueBuf), dcounts, nChunks, sliceLen, table, tableSize - 1,
-                       hshift, probeLen, ctr, gate);
+    const dim3 gDef((nChunks + kBlock / 64 - 1) / (kBlock / 64));
+    if (htm) hipLaunchKernelGGL(k_wave_deferred<true>, gDef, dim3(kBlock), 0, s, static_cast<const DeferredEntry*>(queueBuf), dcounts,
+                                nChunks, sliceLen, table, tableSize - 1, hshift, probeLen, ctr, gate, htmConflicts, ccounts);
+    else hipLaunchKernelGGL(k_wave_deferred<false>, gDef, dim3(kBlock), 0, s, static_cast<const DeferredEntry*>(queueBuf), dcounts,
+                            nChunks, sliceLen, table, tableSize - 1, hshift, probeLen, ctr, gate, nullptr, nullptr);
     return hipGetLastError();
 }
 

@@ -20,6 +20,19 @@ constexpr uint32_t kTableSlack = 16;
 // the whole key.
 __host__ __device__ inline uint64_t home_slot(uint32_t key, uint32_t hshift, uint64_t mask) { return (uint64_t)(key >> hshift) & mask; }
 
+// Home slot in the bucketised table of --algo htm (HTMHashBuild.hpp:41-45,176): a bucket is 4 consecutive 8-byte
+// slots (three tuples + one word of count / overflow link = 32 bytes, one HBM sector), bucket = (key / 3) &
+// (numBuckets - 1); mask = 4 * numBuckets - 1. The three tuple slots are filled by the same index-priority protocol as
+// the open-addressing table with a probe budget of 3: every tuple of a bucket has the same home slot, so the bucket ends
+// up holding the three lowest-indexed tuples in index order and the rest run out of budget = the reference's conflicts.
+__host__ __device__ inline uint64_t home_slot_htm(uint32_t key, uint64_t mask) { return ((uint64_t)(key / 3u) << 2) & mask; }
+template <bool HTM>
+__host__ __device__ inline uint32_t home32(uint32_t key, uint32_t hshift, uint32_t mask32)
+{
+    if constexpr (HTM) return ((key / 3u) << 2) & mask32;
+    else return (key >> hshift) & mask32;
+}
+
 // Optional shard-membership check riding on build and probe (hj_set_shard_check): a tuple is "foreign" when its
 // destination digit ((key - bias) >> shift) & mask differs from id. mask = 0 (and id = 0) switches it off at no
 // cost in branches: every tuple's digit is then 0.
@@ -56,6 +69,8 @@ struct Counters {
     // Build kernel the device-side locality pre-round picked (hj_params.buildVariant 0): written by k_pick_variant,
     // read through the Gate of every build kernel enqueued behind it, reported as hj_result.buildVariant
     unsigned long long variant;
+    // --algo htm (hj_htm.hip): overflow buckets linked, sum of the tuples they hold
+    unsigned long long htmOverflowBuckets, htmOverflowSum;
 };
 
 // Device-side choice between the build variants (hj_build_dev must stay asynchronous: no host read-back). The host
@@ -128,7 +143,32 @@ size_t wave_queue_bytes(uint64_t n, int nCU);   // deferred queue: one slice per
 // slice per chunk (a wavefront's deferred tuples go to ITS slice: no atomics in the kernel).
 hipError_t launch_build_wave(const void* R, bool key32, uint64_t n, uint32_t hshift, uint64_t* table, uint64_t tableSize,
                              uint32_t probeLen, uint64_t idxBase, ShardCheck sc, int nCU, void* boundsBuf, void* queueBuf,
-                             Counters* ctr, Gate gate, int parts, hipEvent_t evPhaseA, hipStream_t s);
+                             Counters* ctr, Gate gate, int parts, hipEvent_t evPhaseA, hipStream_t s,
+                             uint64_t* htmConflicts = nullptr);
+// htmConflicts != nullptr: the bucketised table of --algo htm (home_slot_htm, probeLen must be 3, tuples only); every
+// tuple that runs out of budget is appended as (index << 32 | key) to its chunk's slice of htmConflicts (slices and
+// their counts as wave_conflict_layout describes)
+struct WaveSlices { uint32_t nChunks, sliceLen; const uint32_t* counts; };
+WaveSlices wave_conflict_layout(uint64_t n, int nCU, void* boundsBuf);
+size_t wave_conflict_bytes(uint64_t n, int nCU);
+
+// ---- bucketised table of --algo htm (defined in hj_htm.hip) -----------------
+uint32_t htm_num_buckets(uint64_t rSize);         // nextpow2(rSize / 3 + 1), HTMHashBuild.hpp:61-62
+hipError_t launch_htm_build_global(const uint64_t* R, uint64_t n, uint32_t sliceLen, uint32_t nSlices, uint64_t* table,
+                                   uint64_t tableSlots, uint64_t idxBase, uint64_t* conflicts, uint32_t* ccounts, Counters* ctr,
+                                   hipStream_t s);
+// per-bucket conflict counts -> ovfCount, overflow buckets needed per bucket -> groups (to be scanned in place)
+hipError_t launch_htm_count(const uint64_t* conflicts, const uint32_t* ccounts, uint32_t nSlices, uint32_t sliceLen,
+                            uint32_t numBuckets, unsigned int* ovfCount, uint32_t* groups, hipStream_t s);
+hipError_t launch_htm_chains(const uint64_t* conflicts, const uint32_t* ccounts, uint32_t nSlices, uint32_t sliceLen,
+                             uint64_t* table, uint32_t numBuckets, const unsigned int* ovfCount, const uint32_t* ovfBase,
+                             uint64_t* overflow, uint64_t overflowCapBuckets, Counters* ctr, hipStream_t s);
+void launch_htm_probe(const uint64_t* S, uint64_t n, const uint64_t* table, uint32_t numBuckets, const uint64_t* overflow,
+                      Counters* ctr, hipStream_t s);
+void launch_htm_sums(const uint64_t* table, uint32_t numBuckets, const uint64_t* overflow, Counters* ctr, hipStream_t s);
+// exclusive scan of a uint32 array in place (defined in hj_prj.hip); sums: ceil(n / 4096) + 1 words of workspace
+size_t scan_workspace_words(uint64_t n);
+hipError_t launch_exclusive_scan_u32(uint32_t* data, uint64_t n, uint32_t* sums, hipStream_t s);
 
 // ---- PRJ (defined in hj_prj.hip) -------------------------------------------
 struct PrjPlan {

@@ -985,6 +985,18 @@ hipError_t launch_shard_scatter_ordered(const uint64_t* in, uint64_t n, uint32_t
     return hipGetLastError();
 }
 
+size_t scan_workspace_words(uint64_t n) { return (size_t)((n + kScanTile - 1) / kScanTile) + 1; }
+
+hipError_t launch_exclusive_scan_u32(uint32_t* data, uint64_t n, uint32_t* sums, hipStream_t s)
+{
+    const uint64_t blocks = (n + kScanTile - 1) / kScanTile;
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)blocks), dim3(kBlock), 0, s, data, n, sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, s, sums, (uint32_t)blocks);
+    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)blocks), dim3(kBlock), 0, s, data, n, sums);
+    return hipGetLastError();
+}
+
 hipError_t prj_set_attributes()
 {
     // per device (hj_create calls this with its device current): the LDS join table and the stable split's staging

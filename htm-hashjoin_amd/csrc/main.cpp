@@ -6,8 +6,10 @@
 //   ./main --algo prj    --rSize 1073741824 --dataDistr local_shuffle --shuffleRange 1024
 //
 // --algo values:
-//   atomic | htm | hip-atomic   open-addressing build+probe on the GPU (the TSX /
-//                               CAS insert loops replaced by the index-priority kernels)
+//   atomic | hip-atomic         open-addressing build+probe on the GPU (the CAS insert loop
+//                               replaced by the index-priority kernels)
+//   htm                         the reference's bucketised table (three tuples per 32-byte bucket,
+//                               overflow chains) on the GPU, TSX replaced by the same protocol
 //   prj | hip-prj | PRO         radix-partitioned join on the GPU
 //   auto                        samples R for locality and runs one of the two above
 //                               (the reference's adaptive idea, HTMHashBuild.hpp:98-154);
@@ -221,8 +223,23 @@ int main(int argc, char* argv[])
         }
         if (gpuAuto) gpuPRJ = r.algoUsed == HJ_ALGO_PRJ;     // print the fields of the path that ran
         const double mt = (double)(p.rSize + (S ? sSize : 0)) / r.total_us;
+        if (p.algo == "htm") {
+            // the reference's htm line, field for field (HTMHashBuild.hpp:417-452). There are no transactions here, so
+            // none fail; conflictCount = tuples that found their bucket full; outputSum = buckets + overflow chains
+            std::cout << "{\"algo\": \"htm\",\"rSize\": " << p.rSize << ", \"transactionSize\": " << p.transactionSize
+                      << ", \"probeLength\": " << p.probeLength << ", \"hashBuildTimeInMicroseconds\": " << (uint64_t)r.total_us
+                      << ", \"firstRoundTime\": 0, \"firstRoundFailureFraction\": 0, \"conflictCount\": " << r.conflicts
+                      << ", \"failedTransactions\": 0, \"failedTransactionPercentage\": 0, \"totalFailedPercentage\": "
+                      << (double)r.conflicts / (double)p.rSize;
+            if (p.probe) std::cout << ", \"totalMatches\": " << r.totalMatches;
+            std::cout << ", \"inputSum\": " << r.inputSum << ", \"outputSum\": " << r.outputSum
+                      << ", \"device\": \"hip\", \"numBuckets\": " << r.htmBuckets << ", \"overflowBuckets\": " << r.htmOverflowBuckets
+                      << ", \"sSize\": " << (S ? sSize : 0) << ", \"mtuples_per_s\": " << mt << ", \"build_us\": " << r.build_us
+                      << ", \"probe_us\": " << r.probe_us << ", \"h2d_us\": " << r.h2d_us << "}" << std::endl;
+            hj_destroy(ctx);
+            continue;
+        }
         std::cout << "{\"algo\": \"" << p.algo << "\",\"rSize\": " << p.rSize;
-        if (p.algo == "htm") std::cout << ", \"transactionSize\": " << p.transactionSize;
         std::cout << ", \"probeLength\": " << p.probeLength << ", \"hashBuildTimeInMicroseconds\": " << (uint64_t)r.total_us;
         if (!gpuPRJ) std::cout << ", \"conflicts\": " << r.conflicts;
         if (p.probe) std::cout << ", \"totalMatches\": " << r.totalMatches;

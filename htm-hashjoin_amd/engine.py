@@ -20,6 +20,10 @@ from . import _lib
 from ._lib import lib, hj_params, hj_result
 
 
+# struct Bucket, HTMHashBuild.hpp:41-45 (32 bytes)
+BUCKET_DTYPE = np.dtype([("tuples", np.uint64, 3), ("count", np.uint32), ("nextIndex", np.uint32)])
+
+
 class HashJoinError(RuntimeError):
     def __init__(self, status, detail=""):
         self.status = status
@@ -137,6 +141,20 @@ class HashJoinContext:
         self._check(lib.hj_export_table(self._h, out.ctypes.data, tableSize))
         return out
 
+    def export_buckets(self, numBuckets):
+        """HTM table as the reference's Bucket structs: (buckets[numBuckets], overflows[1 + used]); overflows[0] is unused,
+        nextIndex is 1-based (HTMHashBuild.hpp:41-45, 231-279)."""
+        used = C.c_uint64(0)
+        buckets = np.zeros(numBuckets, dtype=BUCKET_DTYPE)
+        # first call learns the number of overflow buckets (no overflow buffer handed over), second one copies them
+        rc = lib.hj_export_buckets(self._h, buckets.ctypes.data, numBuckets, None, 0, C.byref(used))
+        if rc != _lib.HJ_OK and used.value == 0:
+            self._check(rc)
+        overflows = np.zeros(used.value + 1, dtype=BUCKET_DTYPE)
+        self._check(lib.hj_export_buckets(self._h, buckets.ctypes.data, numBuckets, overflows.ctypes.data,
+                                          overflows.size, C.byref(used)))
+        return buckets, overflows
+
     # ---- raw device memory (hosts without a HIP runtime of their own) -------
     def dev_alloc(self, nbytes):
         p = C.c_void_p()
@@ -203,11 +221,25 @@ def AtomicHashBuild(relR, rSize, relS=None, sSize=0, scaleOutput=2, numPartition
 
 def HTMHashBuild(relR, rSize, relS=None, sSize=0, transactionSize=16, scaleOutput=2, numPartitions=64,
                  probeLength=4, device=0):
-    """HTMHashBuild.hpp:54-60. The TSX transaction groups are replaced outright by the
-    index-priority kernels; transactionSize is accepted and echoed."""
-    out = _operator("htm", relR, rSize, relS, sSize, device, scaleOutput=scaleOutput,
-                    numPartitions=numPartitions, probeLength=probeLength, transactionSize=transactionSize)
-    out["transactionSize"] = transactionSize
+    """HTMHashBuild.hpp:54-60: the bucketised table (three tuples per 32-byte bucket, bucket = (key/3) & mask, conflicts
+    chained into overflow buckets). The TSX transaction groups are replaced outright by the index-priority fill, so
+    there are no aborted transactions to report (failedTransactions = 0); transactionSize is accepted and echoed. Returns
+    the reference's JSON fields (:417-452) in its order."""
+    relR = np.asarray(relR, dtype=np.uint64)[:rSize]
+    if relS is not None:
+        relS = np.asarray(relS, dtype=np.uint64)[:sSize]
+    with HashJoinContext(device) as ctx:
+        r = ctx.run("htm", relR, relS, scaleOutput=scaleOutput, numPartitions=numPartitions, probeLength=probeLength,
+                    transactionSize=transactionSize)
+    out = {"algo": "htm", "rSize": r["rSize"], "transactionSize": transactionSize, "probeLength": probeLength,
+           "hashBuildTimeInMicroseconds": int(r["total_us"]), "firstRoundTime": 0, "firstRoundFailureFraction": 0.0,
+           "conflictCount": r["conflicts"], "failedTransactions": 0, "failedTransactionPercentage": 0.0,
+           "totalFailedPercentage": r["conflicts"] / max(r["rSize"], 1)}
+    if relS is not None:
+        out["totalMatches"] = r["totalMatches"]
+    out["inputSum"] = r["inputSum"]
+    out["outputSum"] = r["outputSum"]
+    out["detail"] = r
     return out
 
 

@@ -43,14 +43,20 @@ typedef enum {
     HJ_ERR_STATE           = -7   /* call order violated (e.g. probe w/o build)*/
 } hj_status;
 
-/* Which reference operator the call stands in for. All of NOCC/ATOMIC/HTM run
- * the same order-deterministic open-addressing kernels (Intel TSX and the racy
- * store are replaced outright); they differ only in the reported name and in
- * which checksum quirk outputSum follows (see hj_result). */
+/* Which reference operator the call stands in for. NOCC and ATOMIC run the same
+ * order-deterministic open-addressing kernels (the racy store and the CAS loop
+ * replaced outright) and differ only in which checksum quirk outputSum follows
+ * (see hj_result). HTM builds the reference's OTHER table: 32-byte buckets of
+ * three tuples, bucket = (key / 3) & (numBuckets - 1), numBuckets =
+ * nextpow2(rSize / 3 + 1), tuples beyond the third ("conflicts") chained into
+ * overflow buckets, probe = bucket + chain (HTMHashBuild.hpp:41-45, 61-62, 176-183,
+ * 231-279, 291-305); Intel TSX is replaced outright by the index-priority fill,
+ * so a bucket holds its three lowest-indexed tuples whatever the scheduling. */
 typedef enum {
     HJ_ALGO_NOCC   = 0,  /* NoCCHashBuild   (NoCCHashBuild.hpp:13-151)   */
     HJ_ALGO_ATOMIC = 1,  /* AtomicHashBuild (AtomicHashBuild.hpp:14-157) */
-    HJ_ALGO_HTM    = 2,  /* HTMHashBuild    (HTMHashBuild.hpp:54-464)    */
+    HJ_ALGO_HTM    = 2,  /* HTMHashBuild    (HTMHashBuild.hpp:54-464): bucketised table + overflow chains;
+                            rSize need not be a power of two; totalMatches = true join cardinality */
     HJ_ALGO_PRJ    = 3,  /* mc PRO          (mc/src/parallel_radix_join.c:1305) */
     HJ_ALGO_AUTO   = 4   /* the reference's adaptive idea (README.md:6, the sampling pre-round of
                             HTMHashBuild.hpp:98-154 and its 0.4 % / 2 % thresholds :209-210): sample R for
@@ -117,6 +123,12 @@ typedef struct {
                                  destination is another shard (0 when the check is off) */
     double   prjScatterPass1R_us; /* PRJ: device time of the pass-1 scatter of R alone (the
                                  dominant kernel: 8 B read + 4 B written per tuple)      */
+    /* HJ_ALGO_HTM: conflicts = the reference's conflictCount (tuples that found their
+     * bucket full, HTMHashBuild.hpp:181-183, :225-228), tableSumFull = sum of the tuples in
+     * primary buckets, outputSum = tableSumFull + htmOverflowSum (== inputSum) */
+    uint64_t htmBuckets;          /* numBuckets                                           */
+    uint64_t htmOverflowBuckets;  /* overflow buckets linked into chains (:231-279)       */
+    uint64_t htmOverflowSum;      /* sum of the tuples they hold (== conflictSum)         */
 } hj_result;
 
 typedef struct hj_ctx hj_ctx;
@@ -177,6 +189,16 @@ int hj_fetch_result(hj_ctx *ctx, hj_result *out);
 /* Copies the open-addressing table to host in the reference's format
  * (tableSize slots, value = key, 0 = empty). */
 int hj_export_table(hj_ctx *ctx, uint64_t *host_table, uint64_t tableSize);
+/* HJ_ALGO_HTM: copies the bucket table to host as the reference's `struct Bucket
+ * {uint64_t tuples[3]; uint32_t count; uint32_t nextIndex;}` (HTMHashBuild.hpp:41-45,
+ * 32 bytes): host_buckets[numBuckets] and host_overflows[0 .. *nOverflow] (index 0
+ * unused, nextIndex is 1-based, 0 = end of chain; overflowCap >= *nOverflow + 1
+ * entries; pass NULL / 0 to learn *nOverflow first). A chain's head is its newest
+ * overflow bucket, as in the reference; the physical overflow indices are this
+ * library's (a bucket's overflow buckets are neighbours), not the reference's
+ * creation order. */
+int hj_export_buckets(hj_ctx *ctx, void *host_buckets, uint64_t numBuckets,
+                      void *host_overflows, uint64_t overflowCap, uint64_t *nOverflow);
 
 /* ---- multi-GPU sharding helpers (new design) ---------------- */
 /* dest(key) = ((key - b) >> d) & (nShards-1), nShards a power of two <= 64, with d = mode & 0xFF the bit position

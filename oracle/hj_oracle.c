@@ -360,6 +360,164 @@ int orc_build_probe_mt(const uint64_t *R, uint64_t rSize,
 }
 
 /* ------------------------------------------------------------------------ */
+/* HTM bucketised table, sequential order (HTMHashBuild.hpp)                  */
+/* ------------------------------------------------------------------------ */
+static uint32_t next_pow2_u32(uint32_t v)
+{   /* NEXT_POW_2, HTMHashBuild.hpp:29-38 */
+    v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; v++;
+    return v;
+}
+
+/* the chain builder and the checksum walk exactly as written (:231-279, :322-342), for outputSumAsWritten.
+ * Works on private copies: it mutates buckets through its `Bucket&` assignments. */
+static uint64_t htm_output_sum_as_written(const uint64_t *R, uint64_t rSize, const orc_bucket *b0, uint32_t numBuckets,
+                                          const uint64_t *conflicts, const uint32_t *conflictCounts,
+                                          uint32_t numPartitions, uint32_t inputPartitionSize, uint64_t conflictCount,
+                                          uint64_t conflictSum)
+{
+    uint32_t tableMask = numBuckets - 1;
+    orc_bucket *buckets = (orc_bucket *)malloc((size_t)numBuckets * sizeof(orc_bucket));
+    orc_bucket *overflows = (orc_bucket *)calloc((size_t)conflictCount + 2, sizeof(orc_bucket));
+    if (!buckets || !overflows) { free(buckets); free(overflows); return 0; }
+    memcpy(buckets, b0, (size_t)numBuckets * sizeof(orc_bucket));
+    int curCounter = 1;
+    for (uint32_t i = 0; i < numPartitions; i++) {                         /* :234 */
+        uint32_t conflictPartitionStart = inputPartitionSize * i;
+        for (uint32_t j = conflictPartitionStart; j < conflictPartitionStart + conflictCounts[i]; j++) {
+            uint32_t slot = (uint32_t)(R[i < rSize ? i : 0] / 3) & tableMask;   /* :237 relR[i], i = partition index */
+            if (buckets[slot].count == 3) {
+                int nextIndex = (int)buckets[slot].nextIndex;
+                if (nextIndex == 0) {
+                    buckets[slot].nextIndex = (uint32_t)curCounter;
+                    overflows[curCounter].count = 1;
+                    overflows[curCounter].tuples[0] = conflicts[j];
+                    curCounter += 1;
+                } else {
+                    orc_bucket *curBucket = &overflows[nextIndex];          /* Bucket& curBucket */
+                    if (curBucket->count == 3) {
+                        *curBucket = overflows[curCounter];                 /* :249 assigns through the reference */
+                        curBucket->nextIndex = buckets[slot].nextIndex;
+                        buckets[slot].nextIndex = (uint32_t)curCounter;
+                        curCounter += 1;
+                        curBucket->count = 1;
+                        curBucket->tuples[0] = conflicts[j];
+                    } else {
+                        curBucket->tuples[curBucket->count] = conflicts[j];
+                        curBucket->count += 1;
+                    }
+                }
+            } else {
+                buckets[slot].tuples[buckets[slot].count] = conflicts[j];
+                buckets[slot].count++;
+            }
+        }
+    }
+    /* :322-342: `Bucket& curBucket = buckets[i]; ... curBucket = overflows[curBucket.nextIndex]` copies the overflow
+     * bucket over buckets[i] while walking; a chain that reaches itself would not end, so the walk is capped */
+    uint64_t sum = 0;
+    for (uint32_t i = 0; i < numBuckets; i++) {
+        orc_bucket *curBucket = &buckets[i];
+        for (uint64_t guard = 0; guard <= conflictCount + 1; guard++) {
+            for (uint32_t j = 0; j < curBucket->count; j++) sum += curBucket->tuples[j];
+            if (curBucket->nextIndex == 0) break;
+            *curBucket = overflows[curBucket->nextIndex];
+        }
+    }
+    free(buckets); free(overflows);
+    return sum + 0 /* failedTransactionSum with TM_RETRY, :366 */ + conflictSum;   /* :452 */
+}
+
+int orc_htm_build_probe_seq(const uint64_t *R, uint64_t rSize, const uint64_t *S, uint64_t sSize,
+                            uint32_t numPartitions, orc_htm_result *res,
+                            orc_bucket *buckets_out, orc_bucket *overflows_out)
+{
+    memset(res, 0, sizeof(*res));
+    if (rSize == 0 || rSize > 0xFFFFFFFFull || numPartitions == 0) return -1;
+    uint32_t numBuckets = (uint32_t)(rSize / 3 + 1);                     /* :61 */
+    numBuckets = next_pow2_u32(numBuckets);                              /* :62 */
+    uint32_t tableMask = numBuckets - 1;                                 /* :96 */
+    uint32_t inputPartitionSize = (uint32_t)(rSize / numPartitions);     /* :63 */
+    if (inputPartitionSize == 0) { inputPartitionSize = (uint32_t)rSize; numPartitions = 1; }
+    orc_bucket *buckets = (orc_bucket *)calloc(numBuckets, sizeof(orc_bucket));        /* :65-72 */
+    uint64_t *conflicts = (uint64_t *)calloc(rSize, sizeof(uint64_t));                 /* :79 */
+    uint32_t *conflictCounts = (uint32_t *)calloc(numPartitions + 1, sizeof(uint32_t)); /* :80 */
+    if (!buckets || !conflicts || !conflictCounts) { free(buckets); free(conflicts); free(conflictCounts); return -1; }
+
+    /* :157-215 with every transaction committing; blocked_range(0, rSize, inputPartitionSize) cuts R into chunks of
+     * inputPartitionSize tuples (a last shorter one if rSize is not a multiple); chunk p's conflicts are stored from
+     * conflicts[inputPartitionSize * p] */
+    uint64_t conflictCount = 0, conflictSum = 0;
+    for (uint64_t begin = 0, p = 0; begin < rSize; begin += inputPartitionSize, p++) {
+        uint64_t end = begin + inputPartitionSize < rSize ? begin + inputPartitionSize : rSize;
+        uint32_t pid = p < numPartitions ? (uint32_t)p : numPartitions - 1;   /* a ragged tail joins the last partition's list */
+        for (uint64_t i = begin; i < end; i++) {
+            uint32_t slot = (uint32_t)(R[i] / 3) & tableMask;             /* :176 */
+            if (buckets[slot].count != 3) {
+                buckets[slot].tuples[buckets[slot].count++] = R[i];       /* :178 */
+            } else {
+                conflicts[(uint64_t)inputPartitionSize * pid + conflictCounts[pid]++] = R[i];   /* :180 */
+                conflictCount++; conflictSum += R[i];
+            }
+        }
+    }
+    uint64_t asWritten = htm_output_sum_as_written(R, rSize, buckets, numBuckets, conflicts, conflictCounts, numPartitions,
+                                                   inputPartitionSize, conflictCount, conflictSum);
+
+    /* :231-279 as intended: each conflict is chained to ITS OWN bucket; a full head gets a new head in front of it */
+    orc_bucket *overflows = (orc_bucket *)calloc((size_t)conflictCount + 2, sizeof(orc_bucket));
+    if (!overflows) { free(buckets); free(conflicts); free(conflictCounts); return -1; }
+    uint32_t curCounter = 1;
+    for (uint32_t i = 0; i < numPartitions; i++) {
+        uint64_t start = (uint64_t)inputPartitionSize * i;
+        for (uint64_t j = start; j < start + conflictCounts[i]; j++) {
+            uint32_t slot = (uint32_t)(conflicts[j] / 3) & tableMask;
+            if (buckets[slot].count == 3) {
+                uint32_t nextIndex = buckets[slot].nextIndex;
+                if (nextIndex == 0 || overflows[nextIndex].count == 3) {
+                    overflows[curCounter].nextIndex = nextIndex;          /* new head, linked to the old one */
+                    overflows[curCounter].count = 1;
+                    overflows[curCounter].tuples[0] = conflicts[j];
+                    buckets[slot].nextIndex = curCounter;
+                    curCounter += 1;
+                } else {
+                    overflows[nextIndex].tuples[overflows[nextIndex].count++] = conflicts[j];
+                }
+            } else {
+                buckets[slot].tuples[buckets[slot].count++] = conflicts[j];
+            }
+        }
+    }
+
+    /* probe, :291-305 (the BUILD_OVERFLOW_TABLE branch): bucket, then its chain */
+    uint64_t matches = 0;
+    if (S) {
+        for (uint64_t i = 0; i < sSize; i++) {
+            const orc_bucket *cur = &buckets[(uint32_t)(S[i] / 3) & tableMask];
+            for (;;) {
+                for (uint32_t j = 0; j < cur->count; j++) if (cur->tuples[j] == S[i]) matches++;
+                if (cur->nextIndex == 0) break;
+                cur = &overflows[cur->nextIndex];
+            }
+        }
+    }
+    uint64_t inputSum = 0, bucketSum = 0, overflowSum = 0;
+    for (uint64_t i = 0; i < rSize; i++) inputSum += R[i];               /* :312-320 */
+    for (uint32_t i = 0; i < numBuckets; i++)
+        for (uint32_t j = 0; j < buckets[i].count; j++) bucketSum += buckets[i].tuples[j];
+    for (uint32_t i = 1; i < curCounter; i++)
+        for (uint32_t j = 0; j < overflows[i].count; j++) overflowSum += overflows[i].tuples[j];
+
+    res->rSize = rSize; res->sSize = S ? sSize : 0; res->numBuckets = numBuckets;
+    res->conflictCount = conflictCount; res->conflictSum = conflictSum; res->overflowBuckets = curCounter - 1;
+    res->totalMatches = matches; res->inputSum = inputSum; res->bucketSum = bucketSum; res->overflowSum = overflowSum;
+    res->outputSum = bucketSum + overflowSum; res->outputSumAsWritten = asWritten;
+    if (buckets_out) memcpy(buckets_out, buckets, (size_t)numBuckets * sizeof(orc_bucket));
+    if (overflows_out) memcpy(overflows_out, overflows, (size_t)(conflictCount + 1) * sizeof(orc_bucket));
+    free(buckets); free(conflicts); free(conflictCounts); free(overflows);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
 /* PRJ                                                                       */
 /* ------------------------------------------------------------------------ */
 #define HASH_BIT_MODULO(K, MASK, NBITS) (((K) & (MASK)) >> (NBITS)) /* :59 */

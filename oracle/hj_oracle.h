@@ -7,13 +7,21 @@
  * against the reference's semantics.  Nothing under htm-hashjoin_amd/ may
  * include, link or call it.
  *
- * Parity status: PINNED.
+ * Parity status: PINNED (HTM bucket path: pinned on unique keys only, see below).
  *   - nocc/atomic path: pinned by the reference's own committed run logs
  *     (experiments/new_backup/probe_log*, AtomicsVsHTMVsNoCC_log*,
  *     experiments/overflow_log1) -- see tests/golden/reference_logs.json --
  *     and by SURVEY.md Appendix B/C values.  The reference's main.cpp path
  *     itself is NOT buildable here (it needs Intel TBB headers, which this
  *     image lacks), so no oracle/_ref binary exists for it.
+ *   - HTM bucketised path (orc_htm_build_probe_seq): HTMHashBuild.hpp needs TBB and
+ *     RTM and cannot be built here. Pinned by the `htm` lines of the reference's logs
+ *     (probe_log*, AtomicsVsHTMVsNoCC_log*: conflictCount 0, totalMatches = rSize,
+ *     inputSum = outputSum = N(N+1)/2 on unique keys). On duplicate keys the
+ *     reference's own numbers are run dependent (TSX aborts reorder the inserts;
+ *     experiments/overflow_log1 vs _log2 come from an older code version and differ
+ *     line by line): conflictCount is order independent and restated exactly, the
+ *     chain contents follow sequential input order -- PARITY UNPINNED there.
  *   - PRJ path: pinned by oracle/_ref/mchashjoins, compiled from the
  *     reference's mc/src/ sources where they lie (oracle/Makefile), and by
  *     experiments/new_backup/motivation_log1:8 (Results = 549688705024).
@@ -100,6 +108,54 @@ int orc_build_probe_mt(const uint64_t *R, uint64_t rSize,
                        const uint64_t *S, uint64_t sSize,
                        uint32_t probeLength, uint32_t numPartitions,
                        int nthreads, int atomic, orc_result *res);
+
+/* ---- HTM bucketised table (HTMHashBuild.hpp) ------------------------------ */
+
+/* Bucket, HTMHashBuild.hpp:41-45: three tuples, their count, and the 1-based index of
+ * the first overflow bucket of the chain (0 = none). 32 bytes. */
+typedef struct {
+    uint64_t tuples[3];
+    uint32_t count;
+    uint32_t nextIndex;
+} orc_bucket;
+
+typedef struct {
+    uint64_t rSize, sSize, numBuckets;
+    uint64_t conflictCount;   /* tuples that found their bucket full (:181-183, :225-228)              */
+    uint64_t conflictSum;     /* sum of those tuples (:369-380)                                         */
+    uint64_t overflowBuckets; /* overflow buckets allocated (curCounter - 1, :232)                      */
+    uint64_t totalMatches;    /* probe over bucket + chain (:291-305, the BUILD_OVERFLOW_TABLE branch)  */
+    uint64_t inputSum;        /* :312-320                                                               */
+    uint64_t bucketSum;       /* sum of the tuples in the primary buckets                               */
+    uint64_t overflowSum;     /* sum of the tuples in overflow buckets (== conflictSum: every conflict
+                                 is chained to its own bucket)                                          */
+    uint64_t outputSum;       /* bucketSum + overflowSum: the checksum the field exists for
+                                 (== inputSum). NOT what :452 prints when conflicts > 0, see below      */
+    uint64_t outputSumAsWritten; /* `sum + failedTransactionSum + conflictSum` evaluated over the code
+                                 exactly AS WRITTEN, bugs included (see orc_htm_build_probe_seq);
+                                 equals inputSum when conflictCount == 0, which is all the
+                                 reference's logs pin                                                   */
+} orc_htm_result;
+
+/* Sequential-order restatement of HTMHashBuild (HTMHashBuild.hpp:54-464) with every
+ * transaction committing (TSX is replaced, not emulated: an aborted group is retried
+ * serially by the reference, :219-238, which on one thread is just the same inserts later):
+ *   numBuckets = nextpow2(rSize/3 + 1) (:61-62); slot = (key/3) & (numBuckets-1) (:176);
+ *   bucket not full -> tuples[count++] = key, else the tuple is a conflict of its input
+ *   partition (:177-183), partitions = rSize/numPartitions consecutive tuples (:63);
+ *   then the overflow chains (:231-279) and the probe that walks bucket + chain (:291-305).
+ * Two lines of the chain builder cannot mean what they say and are restated as INTENDED
+ * (the as-written behaviour is evaluated separately for outputSumAsWritten):
+ *   :245 `slot = (relR[i]/3) & tableMask` hashes relR[PARTITION INDEX], not the conflict
+ *        being chained (conflicts[j]): as written every conflict of partition i hangs off
+ *        the bucket of the i-th tuple of R. Intended: the conflict's own bucket.
+ *   :257 `curBucket = overflows[curCounter]` assigns THROUGH the reference into the full
+ *        head bucket, wiping its three tuples, instead of starting a new head. Intended:
+ *        a new head bucket linked to the old one.
+ * buckets_out (numBuckets) / overflows_out (rSize + 1, index 0 unused) may be NULL. */
+int orc_htm_build_probe_seq(const uint64_t *R, uint64_t rSize, const uint64_t *S, uint64_t sSize,
+                            uint32_t numPartitions, orc_htm_result *res,
+                            orc_bucket *buckets_out, orc_bucket *overflows_out);
 
 /* ---- PRJ (mc/src/parallel_radix_join.c) ---------------------------------- */
 

@@ -31,6 +31,8 @@ def _load():
                                        C.c_int, C.c_int, C.POINTER(OrcResult)]
     lib.orc_prj_join.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32,
                                  C.POINTER(OrcPrjResult)]
+    lib.orc_htm_build_probe_seq.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32,
+                                            C.POINTER(OrcHtmResult), C.c_void_p, C.c_void_p]
     lib.orc_true_cardinality.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
     lib.orc_true_cardinality.restype = C.c_uint64
     return lib
@@ -44,6 +46,19 @@ class OrcResult(C.Structure):
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class OrcHtmResult(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "rSize", "sSize", "numBuckets", "conflictCount", "conflictSum", "overflowBuckets", "totalMatches", "inputSum",
+        "bucketSum", "overflowSum", "outputSum", "outputSumAsWritten")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+# Bucket, HTMHashBuild.hpp:41-45 (32 bytes)
+BUCKET_DTYPE = np.dtype([("tuples", np.uint64, 3), ("count", np.uint32), ("nextIndex", np.uint32)])
 
 
 class OrcPrjResult(C.Structure):
@@ -129,6 +144,48 @@ def sharded_reference(relR, relS, n_shards, probe_length=4, digit_shift=0, one_b
         for k in tot:
             tot[k] += r[k]
     return tot
+
+
+def htm_build_probe_seq(relR, relS=None, num_partitions=64, want_buckets=False):
+    """HTMHashBuild in sequential order (orc_htm_build_probe_seq). With want_buckets the dict also carries the primary
+    buckets and the overflow buckets (index 0 unused) as BUCKET_DTYPE arrays."""
+    relR = np.ascontiguousarray(relR, dtype=np.uint64)
+    res = OrcHtmResult()
+    s_ptr, s_n = (None, 0)
+    if relS is not None:
+        relS = np.ascontiguousarray(relS, dtype=np.uint64)
+        s_ptr, s_n = relS.ctypes.data, relS.size
+    nb = 1
+    while nb < relR.size // 3 + 1:
+        nb *= 2
+    buckets = np.zeros(nb, dtype=BUCKET_DTYPE) if want_buckets else None
+    overflows = np.zeros(relR.size + 1, dtype=BUCKET_DTYPE) if want_buckets else None
+    rc = _lib.orc_htm_build_probe_seq(relR.ctypes.data, relR.size, s_ptr, s_n, num_partitions, C.byref(res),
+                                      buckets.ctypes.data if want_buckets else None,
+                                      overflows.ctypes.data if want_buckets else None)
+    assert rc == 0
+    d = res.as_dict()
+    assert d["numBuckets"] == nb
+    if want_buckets:
+        d["buckets"] = buckets
+        d["overflows"] = overflows[: d["overflowBuckets"] + 1]
+    return d
+
+
+def htm_chains(buckets, overflows):
+    """Logical view of a bucket table: per primary bucket the tuples it holds, then those of its overflow chain in walk
+    order (head = newest overflow bucket). Physical overflow indices may differ between two builds of the same table;
+    this view may not. Returns (counts, flat tuple array, offsets)."""
+    out, off = [], [0]
+    for b in range(buckets.size):
+        cur = buckets[b]
+        while True:
+            out.extend(int(x) for x in cur["tuples"][: cur["count"]])
+            if cur["nextIndex"] == 0:
+                break
+            cur = overflows[cur["nextIndex"]]
+        off.append(len(out))
+    return np.array(out, dtype=np.uint64), np.array(off, dtype=np.int64)
 
 
 def build_probe_mt(relR, relS, probe_length=4, num_partitions=64, nthreads=1, atomic=False):

@@ -18,7 +18,7 @@ import re
 REF = os.environ.get("HJ_REFERENCE", "/root/reference")
 EXP = os.path.join(REF, "experiments")
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_logs.json")
-KEEP = ("algo", "rSize", "probeLength", "transactionSize", "conflicts", "totalMatches", "inputSum", "outputSum")
+KEEP = ("algo", "rSize", "probeLength", "transactionSize", "conflicts", "conflictCount", "totalMatches", "inputSum", "outputSum")
 
 
 def json_lines(path):

@@ -194,7 +194,7 @@ def test_build_only_and_empty_probe(ctx):
     n = 1 << 12
     R = oracle.generate_data("uniform", n, n, 16)
     want = oracle.build_probe_seq(R, None, 4)
-    got = ctx.run("htm", R, None)
+    got = ctx.run("atomic", R, None)
     check_oa(got, want)
     assert got["totalMatches"] == 0 and got["sSize"] == 0
 
@@ -223,9 +223,93 @@ def test_operator_mirrors(ctx):
     j = hj.AtomicHashBuild(R, n, S, n, 2, 64, 4)
     assert (j["conflicts"], j["totalMatches"], j["inputSum"], j["outputSum"]) == (0, n, tri, tri)
     j = hj.HTMHashBuild(R, n, S, n, 16, 2, 64, 4)
-    assert j["transactionSize"] == 16 and j["totalMatches"] == n
+    assert list(j)[:12] == ["algo", "rSize", "transactionSize", "probeLength", "hashBuildTimeInMicroseconds", "firstRoundTime",
+                            "firstRoundFailureFraction", "conflictCount", "failedTransactions", "failedTransactionPercentage",
+                            "totalFailedPercentage", "totalMatches"]                 # HTMHashBuild.hpp:417-452
+    assert (j["transactionSize"], j["conflictCount"], j["totalMatches"], j["inputSum"], j["outputSum"]) == (16, 0, n, tri, tri)
     j = hj.PRO(R, S)
     assert j["matches"] == n
+
+
+# ---- the bucketised table of --algo htm ---------------------------------------------------------
+@pytest.mark.parametrize("variant", [0, 1, 3])
+@pytest.mark.parametrize("dist,window", [("uniform", 16), ("random", 16), ("sorted", 16), ("shuffle", 16),
+                                         ("local_shuffle", 1024), ("local_shuffle", 65536)])
+@pytest.mark.parametrize("n", [1 << 10, 1 << 16, 1 << 20])
+def test_htm_bucket_table_matches_sequential_oracle(ctx, dist, window, n, variant):
+    """HJ_ALGO_HTM against the sequential restatement of HTMHashBuild.hpp (oracle.htm_build_probe_seq): every counter,
+    the primary buckets tuple for tuple (a bucket holds its three lowest-indexed tuples in input order), and every
+    overflow chain in walk order (head = newest overflow bucket). buildVariant 3 = the LDS rings, 1 = global atomics,
+    0 = whichever the locality pre-round picks: same table."""
+    R = oracle.generate_data(dist, n, n, window)
+    S = oracle.relS_for(dist, R)
+    want = oracle.htm_build_probe_seq(R, S, want_buckets=True)
+    got = ctx.run("htm", R, S, buildVariant=variant)
+    assert got["algoUsed"] == "htm" and got["htmBuckets"] == want["numBuckets"]
+    assert (got["conflicts"], got["conflictSum"], got["totalMatches"], got["inputSum"], got["tableSumFull"],
+            got["htmOverflowBuckets"], got["htmOverflowSum"], got["outputSum"]) == (
+        want["conflictCount"], want["conflictSum"], want["totalMatches"], want["inputSum"], want["bucketSum"],
+        want["overflowBuckets"], want["overflowSum"], want["outputSum"])
+    assert got["totalMatches"] == oracle.true_cardinality(R, S)                 # every tuple is stored once: a correct join
+    if variant:
+        assert got["buildVariant"] == variant
+    buckets, overflows = ctx.export_buckets(want["numBuckets"])
+    assert np.array_equal(buckets["tuples"], want["buckets"]["tuples"]) and np.array_equal(buckets["count"], want["buckets"]["count"])
+    assert np.array_equal(buckets["nextIndex"] != 0, want["buckets"]["nextIndex"] != 0)
+    assert overflows.size == want["overflows"].size
+    if n <= 1 << 16:                                                            # chains, logically (physical indices differ by design)
+        a, ao = oracle.htm_chains(buckets, overflows)
+        b, bo = oracle.htm_chains(want["buckets"], want["overflows"])
+        assert np.array_equal(ao, bo) and np.array_equal(a, b)
+    else:                                                                       # same multiset of overflow buckets
+        key = lambda o: np.sort(o[1:].view(np.uint64).reshape(-1, 4)[:, :3].sum(axis=1))          # noqa: E731
+        assert np.array_equal(key(overflows), key(want["overflows"]))
+
+
+def test_htm_heavy_duplicates_odd_sizes_and_split_api(ctx):
+    """Long chains (few keys), sizes that are not powers of two (the bucket hash does not need one), R-only builds, an
+    unaligned device pointer, and a probe side with keys the table never saw."""
+    rng = np.random.default_rng(5)
+    for n, hi in ((1, 2), (7, 3), (1000, 5), (4097, 50), (100_000, 1000), (1 << 15, 1 << 14)):
+        R = rng.integers(1, hi, size=n, dtype=np.uint64)
+        S = rng.integers(1, hi + 5, size=2 * n + 3, dtype=np.uint64)
+        want = oracle.htm_build_probe_seq(R, S, want_buckets=True)
+        for variant in (1, 3):
+            with hj.HashJoinContext(0) as c:
+                dR = c.dev_alloc(n * 8 + 16); dS = c.dev_alloc(S.size * 8 + 16)
+                c.copy_h2d(dR + 8, R); c.copy_h2d(dS + 8, S)
+                c.reserve("htm", n, S.size, buildVariant=variant)
+                c.build(dR + 8, n)
+                c.probe(dS + 8, S.size)
+                c.checksums()
+                got = c.fetch()
+                assert (got["conflicts"], got["totalMatches"], got["inputSum"], got["outputSum"], got["htmOverflowBuckets"]) == (
+                    want["conflictCount"], want["totalMatches"], want["inputSum"], want["inputSum"], want["overflowBuckets"]), (n, hi, variant)
+                buckets, overflows = c.export_buckets(want["numBuckets"])
+                a, ao = oracle.htm_chains(buckets, overflows)
+                b, bo = oracle.htm_chains(want["buckets"], want["overflows"])
+                assert np.array_equal(ao, bo) and np.array_equal(a, b), (n, hi, variant)
+                c.dev_free(dR); c.dev_free(dS)
+
+
+def test_htm_log_pins_at_2p27(ctx):
+    """The `htm` lines of the reference's logs (experiments/new_backup/probe_log*, tests/golden/reference_logs.json):
+    local_shuffle at 2^27 -- conflictCount 0, totalMatches = rSize, inputSum = outputSum = 9007199321849856."""
+    n = 1 << 27
+    R = hj.generate_data("local_shuffle", n, n, 1024)
+    S = hj.generate_data("sorted", n)
+    got = ctx.run("htm", R, S)
+    # (a shuffle window of 1024 is more than the 8 KiB rings hold at 4 slots per 3 keys: the pre-round takes global atomics)
+    assert (got["conflicts"], got["totalMatches"], got["inputSum"], got["outputSum"], got["htmOverflowBuckets"], got["buildVariant"]) == (
+        0, n, 9007199321849856, 9007199321849856, 0, 1)
+    R = hj.generate_data("uniform", n, n, 16)                                   # duplicates at full size: the order-independent count
+    got = ctx.run("htm", R, S)
+    assert got["buildVariant"] == 3                                             # the reference's default window: the LDS rings
+    per = np.bincount(((R // np.uint64(3)) & np.uint64(got["htmBuckets"] - 1)).astype(np.int64), minlength=got["htmBuckets"])
+    assert got["conflicts"] == int(np.maximum(per - 3, 0).sum())
+    assert got["htmOverflowBuckets"] == int(((np.maximum(per - 3, 0) + 2) // 3).sum())
+    assert got["outputSum"] == got["inputSum"] == 9006807263251667
+    assert got["totalMatches"] == int(per.sum()) == n                            # S = 1..N, keys in [1, N]: every R tuple matches once
 
 
 # ---- PRJ ---------------------------------------------------------------------
@@ -730,8 +814,10 @@ def test_main_cli_on_gpu():
     assert (j["conflicts"], j["totalMatches"], j["inputSum"]) == (176864, 871712, 549507039110)
     assert j["outputSum"] == j["inputSum"] and j["device"] == "hip"     # table sum + dropped keys = input sum
     j = run("--algo", "htm", "--transactionSize", 16, "--rSize", 1048576, "--dataDistr", "local_shuffle", "--shuffleRange", 1024)
-    assert (j["algo"], j["transactionSize"], j["conflicts"], j["totalMatches"], j["inputSum"], j["outputSum"]) == (
-        "htm", 16, 0, 1048576, 549756338176, 549756338176)
+    assert (j["algo"], j["transactionSize"], j["conflictCount"], j["failedTransactions"], j["totalMatches"], j["inputSum"],
+            j["outputSum"], j["numBuckets"], j["overflowBuckets"]) == ("htm", 16, 0, 0, 1048576, 549756338176, 549756338176, 1 << 19, 0)
+    j = run("--algo", "htm", "--rSize", 1048576, "--dataDistr", "uniform")           # duplicate keys: buckets overflow into chains
+    assert j["conflictCount"] > 0 and j["overflowBuckets"] > 0 and j["outputSum"] == j["inputSum"] == 549507039110
     j = run("--algo", "atomic", "--rSize", 65536, "--dataDistr", "sorted", "--probe", 0)                 # ENABLE_PROBE 0
     assert "totalMatches" not in j and j["conflicts"] == 0
     j = run("--algo", "auto", "--rSize", 1048576, "--dataDistr", "local_shuffle", "--shuffleRange", 1024)

@@ -80,6 +80,72 @@ def test_reference_log_pins_2p27_local_shuffle(golden_dir):
     assert got["outputSumAtomic"] == atomic["outputSum"]
 
 
+def test_reference_logs_htm_lines_are_consistent(golden_dir):
+    """All 150 `htm` lines of the reference's logs (probe.sh with transactionSize 16 and the probe, AtomicsVsHTMVsNoCC.sh
+    build only; unique keys): no bucket ever overflows, every probe matches, the checksum equals the input sum."""
+    logs = _load(golden_dir, "reference_logs.json")
+    n = 1 << 27
+    tri = n * (n + 1) // 2
+    seen = {(c["probe"], c["conflictCount"], c.get("totalMatches"), c["inputSum"], c["outputSum"])
+            for c in logs["cases"] if c["algo"] == "htm"}
+    assert seen == {(1, 0, n, tri, tri), (0, 0, None, tri, tri)}
+
+
+@pytest.mark.parametrize("dist,window", [("local_shuffle", 1), ("local_shuffle", 1024), ("local_shuffle", 1 << 19),
+                                         ("sorted", 16), ("shuffle", 16)])
+def test_htm_oracle_on_unique_keys_follows_the_log_pins(dist, window):
+    """The distributions of those log lines at a size the CPU suite affords: same closed forms (conflictCount 0,
+    totalMatches = N, outputSum = inputSum = N(N+1)/2, also for the checksum expression evaluated as written)."""
+    n = 1 << 20
+    R = oracle.generate_data(dist, n, n, window)
+    S = oracle.generate_data("sorted", n)
+    got = oracle.htm_build_probe_seq(R, S)
+    tri = n * (n + 1) // 2
+    assert (got["conflictCount"], got["totalMatches"], got["inputSum"], got["outputSum"], got["outputSumAsWritten"]) == (
+        0, n, tri, tri, tri)
+    assert got["numBuckets"] == 1 << 19 and got["overflowBuckets"] == 0
+
+
+@pytest.mark.slow
+def test_htm_oracle_2p27_log_pin(golden_dir):
+    """experiments/new_backup/probe_log*: the htm line for local_shuffle W = 1024 at 2^27, run in full."""
+    logs = _load(golden_dir, "reference_logs.json")
+    want = [c for c in logs["cases"] if c["algo"] == "htm" and c["probe"] == 1 and c["shuffleRange"] == 1024][0]
+    n = want["rSize"]
+    R = oracle.generate_data("local_shuffle", n, n, 1024)
+    S = oracle.generate_data("sorted", n)
+    got = oracle.htm_build_probe_seq(R, S)
+    assert (got["conflictCount"], got["totalMatches"], got["inputSum"], got["outputSumAsWritten"], got["outputSum"]) == (
+        want["conflictCount"], want["totalMatches"], want["inputSum"], want["outputSum"], want["outputSum"])
+
+
+def test_htm_oracle_duplicate_keys_invariants():
+    """Duplicate keys (no reference-held golden: the reference's own numbers are run dependent there): conflictCount is
+    the order-independent sum over buckets of max(0, tuples - 3); every tuple is stored exactly once (bucket or chain),
+    so the probe counts true multiplicities and bucketSum + overflowSum = inputSum."""
+    for dist in ("uniform", "random"):
+        n = 1 << 16
+        R = oracle.generate_data(dist, n, n, 16)
+        S = oracle.relS_for(dist, R)
+        got = oracle.htm_build_probe_seq(R, S, want_buckets=True)
+        b = ((R // np.uint64(3)) & np.uint64(got["numBuckets"] - 1)).astype(np.int64)
+        per = np.bincount(b, minlength=got["numBuckets"])
+        assert got["conflictCount"] == int(np.maximum(per - 3, 0).sum()) > 0
+        assert got["overflowBuckets"] == int(((np.maximum(per - 3, 0) + 2) // 3).sum())
+        assert got["totalMatches"] == oracle.true_cardinality(R, S)
+        assert got["outputSum"] == got["inputSum"] and got["overflowSum"] == got["conflictSum"]
+        assert np.array_equal(got["buckets"]["count"], np.minimum(per, 3).astype(np.uint32))
+        flat, off = oracle.htm_chains(got["buckets"], got["overflows"])
+        assert np.array_equal(np.diff(off), per)                        # bucket + chain hold exactly the bucket's tuples
+        # primary buckets: the first three tuples of the bucket in input order; chain: the rest, newest group first
+        for k in np.flatnonzero(per > 3)[:200]:
+            mine = R[b == k]
+            assert got["buckets"]["tuples"][k].tolist() == mine[:3].tolist()
+            rest, walk = mine[3:].tolist(), flat[off[k] + 3: off[k + 1]].tolist()
+            groups = [rest[i:i + 3] for i in range(0, len(rest), 3)]
+            assert walk == [x for g in reversed(groups) for x in g]
+
+
 @pytest.mark.slow
 def test_reference_log_pin_2p27_uniform_inputsum(golden_dir):
     """experiments/overflow_log1: inputSum of `uniform` at 2^27 (DataGen + glibc rand)."""

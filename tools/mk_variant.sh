@@ -10,7 +10,7 @@ out=$here/tools/variants
 mkdir -p $out/obj_$name
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-value $flags -c $src/$file.hip -o $out/obj_$name/$file.o
 objs=""
-for o in hj_kernels hj_build_own hj_build_wave hj_prj hj_api hj_datagen; do
+for o in hj_kernels hj_build_own hj_build_wave hj_htm hj_prj hj_api hj_datagen; do
   if [ "$o" == "$file" ]; then objs="$objs $out/obj_$name/$file.o"; else objs="$objs $src/$o.o"; fi
 done
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $out/$name.so $objs -lpthread
