@@ -10,5 +10,5 @@ from ._lib import (  # noqa: F401
 )
 from .engine import (  # noqa: F401
     HashJoinError, HashJoinContext, NoCCHashBuild, AtomicHashBuild, HTMHashBuild, PRO,
-    generate_data, device_count, SHARD_ONE_BASED, BUCKET_DTYPE,
+    generate_data, generate_relation, device_count, SHARD_ONE_BASED, BUCKET_DTYPE,
 )

@@ -90,6 +90,7 @@ def _declare(lib):
         "hj_copy_h2d": ([vp, vp, vp, u64], i32),
         "hj_copy_d2h": ([vp, vp, vp, u64], i32),
         "hj_prj_workspace_info": ([u64, u64, u32, P(u64)], i32),
+        "hj_generate_relation": ([C.c_char_p, u64, u64, i32, C.c_double, C.c_uint, vp], i32),
         "hj_generate_data": ([C.c_char_p, u64, u64, i32, C.c_double, vp], i32),
     }
     for name, (args, res) in sig.items():

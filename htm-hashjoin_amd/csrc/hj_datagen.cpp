@@ -116,6 +116,56 @@ void iota1(uint64_t* out, uint64_t n)  // DataGen.hpp:79-85
     for (uint64_t i = 0; i < n; ++i) out[i] = i + 1;
 }
 
+
+// gen_zipf, mc/src/genzipf.c:95-158: random alphabet permutation (:28-53), cumulative LUT (:60-93), one rand() and one
+// binary search per draw (:118-151)
+int gen_zipf(GlibcRand& rng, uint64_t n, uint64_t distinct, double zipfTheta, uint64_t* out)
+{
+    if (distinct == 0 || distinct > 0xFFFFFFFFull || !(zipfTheta >= 0.0)) return HJ_ERR_INVALID;
+    const uint32_t asz = (uint32_t)distinct;
+    std::vector<uint32_t> alphabet(asz);
+    for (uint32_t i = 0; i < asz; ++i) alphabet[i] = i + 1;
+    for (uint32_t i = asz - 1; i > 0; --i) {
+        const unsigned k = (unsigned)((unsigned long)i * (unsigned long)rng.next() / kRandMax);
+        std::swap(alphabet[i], alphabet[k]);
+    }
+    std::vector<double> lut(asz);
+    double scaling = 0.0, sum = 0.0;
+    for (uint32_t i = 1; i <= asz; ++i) scaling += 1.0 / std::pow((double)i, zipfTheta);
+    for (uint32_t i = 1; i <= asz; ++i) { sum += 1.0 / std::pow((double)i, zipfTheta); lut[i - 1] = sum / scaling; }
+    for (uint64_t i = 0; i < n; ++i) {
+        const double r = ((double)rng.next()) / kRandMax;
+        unsigned left = 0, right = asz - 1, pos;
+        if (lut[0] >= r) pos = 0;
+        else {
+            while (right - left > 1) {
+                const unsigned m = (left + right) / 2;
+                if (lut[m] < r) left = m; else right = m;
+            }
+            pos = right;
+        }
+        out[i] = alphabet[pos];
+    }
+    return HJ_OK;
+}
+
+// RAND_RANGE(N), mc/src/generator.c:20
+inline double rand_range(GlibcRand& rng, double n) { return (double)rng.next() / ((double)kRandMax + 1) * n; }
+
+void knuth_shuffle(GlibcRand& rng, uint64_t* t, uint64_t n)      // generator.c:83-93
+{
+    for (int64_t i = (int64_t)n - 1; i > 0; --i) {
+        const int32_t j = (int32_t)rand_range(rng, (double)i);
+        std::swap(t[i], t[j]);
+    }
+}
+
+void random_unique_gen(GlibcRand& rng, uint64_t* t, uint64_t n)  // generator.c:125-136
+{
+    iota1(t, n);
+    knuth_shuffle(rng, t, n);
+}
+
 }  // namespace
 
 extern "C" int hj_generate_data(const char* dist, uint64_t n, uint64_t distinct, int window,
@@ -153,33 +203,40 @@ extern "C" int hj_generate_data(const char* dist, uint64_t n, uint64_t distinct,
     } else if (strcmp(dist, "zipf") == 0) {
         // mc/src/genzipf.c:28-151, keys over [1, distinct]; the reference DataGen
         // branch (:72-77) is an empty stub, so the seed is ours: srand(0) like the rest
-        if (distinct == 0 || distinct > 0xFFFFFFFFull || !(zipfTheta >= 0.0)) return HJ_ERR_INVALID;
-        const uint32_t asz = (uint32_t)distinct;
-        std::vector<uint32_t> alphabet(asz);
-        for (uint32_t i = 0; i < asz; ++i) alphabet[i] = i + 1;
-        for (uint32_t i = asz - 1; i > 0; --i) {
-            const unsigned k = (unsigned)((unsigned long)i * (unsigned long)rng.next() / kRandMax);
-            std::swap(alphabet[i], alphabet[k]);
-        }
-        std::vector<double> lut(asz);
-        double scaling = 0.0, sum = 0.0;
-        for (uint32_t i = 1; i <= asz; ++i) scaling += 1.0 / std::pow((double)i, zipfTheta);
-        for (uint32_t i = 1; i <= asz; ++i) { sum += 1.0 / std::pow((double)i, zipfTheta); lut[i - 1] = sum / scaling; }
-        for (uint64_t i = 0; i < n; ++i) {
-            const double r = ((double)rng.next()) / kRandMax;
-            unsigned left = 0, right = asz - 1, pos;
-            if (lut[0] >= r) pos = 0;
-            else {
-                while (right - left > 1) {
-                    const unsigned m = (left + right) / 2;
-                    if (lut[m] < r) left = m; else right = m;
-                }
-                pos = right;
-            }
-            out[i] = alphabet[pos];
-        }
+        return gen_zipf(rng, n, distinct, zipfTheta, out);
     } else {
         return HJ_ERR_INVALID;  // DataGen.hpp:116-119 prints "Unknown distribution" and exits
+    }
+    return HJ_OK;
+}
+
+extern "C" int hj_generate_relation(const char* kind, uint64_t n, uint64_t maxid, int window, double theta,
+                                    unsigned seed, uint64_t* out)
+{
+    if (!kind || (!out && n)) return HJ_ERR_INVALID;
+    GlibcRand rng(seed);                                         // seed_generator, generator.c:56-61
+    if (strcmp(kind, "pk") == 0) {
+        random_unique_gen(rng, out, n);
+    } else if (strcmp(kind, "pk_lshuffle") == 0) {               // lshuffle, generator.c:96-110
+        if (window <= 0) return HJ_ERR_INVALID;
+        iota1(out, n);
+        for (uint64_t i = 0; i < n; ++i) {
+            const int64_t runway = (int64_t)(n - i);
+            const int mod = runway > window ? window : (int)runway;
+            std::swap(out[i], out[i + (uint64_t)(rng.next() % mod)]);
+        }
+    } else if (strcmp(kind, "fk") == 0) {                        // create_relation_fk, generator.c:408-445
+        if (maxid == 0) return HJ_ERR_INVALID;
+        const uint64_t iters = n / maxid, rem = n % maxid;
+        for (uint64_t i = 0; i < iters; ++i) random_unique_gen(rng, out + maxid * i, maxid);
+        if (rem) random_unique_gen(rng, out + maxid * iters, rem);
+    } else if (strcmp(kind, "nonunique") == 0) {                 // random_gen, generator.c:230-238
+        if (maxid == 0 || maxid > 0x7FFFFFFFull) return HJ_ERR_INVALID;
+        for (uint64_t i = 0; i < n; ++i) out[i] = (uint64_t)(int32_t)rand_range(rng, (double)(int32_t)maxid);
+    } else if (strcmp(kind, "zipf") == 0) {
+        return gen_zipf(rng, n, maxid, theta, out);
+    } else {
+        return HJ_ERR_INVALID;
     }
     return HJ_OK;
 }

@@ -49,6 +49,17 @@ def generate_data(dist, size_in_tuples, distinct_keys=None, local_shuffle_range=
     return out
 
 
+def generate_relation(kind, num_tuples, maxid=None, local_shuffle_range=0, zipf_param=0.0, seed=12345):
+    """mc/src/generator.c: kind = pk | pk_lshuffle | fk | nonunique | zipf (create_relation_*), srand(seed) first
+    (mc seeds R with 12345 and S with 54321, mc/src/main.c:337-338)."""
+    out = np.empty(num_tuples, dtype=np.uint64)
+    rc = lib.hj_generate_relation(kind.encode(), num_tuples, num_tuples if maxid is None else maxid,
+                                  int(local_shuffle_range), float(zipf_param), int(seed), out.ctypes.data)
+    if rc != _lib.HJ_OK:
+        raise HashJoinError(rc, f"hj_generate_relation({kind!r})")
+    return out
+
+
 def _params(algo, scaleOutput=2, numPartitions=64, probeLength=4, transactionSize=16, radixBits=0,
             buildVariant=0):
     p = hj_params()

@@ -264,6 +264,20 @@ int hj_copy_d2h(hj_ctx *ctx, void *dst_host, const void *src_dev, uint64_t bytes
 int hj_generate_data(const char *dist, uint64_t n, uint64_t distinct, int window,
                      double zipfTheta, uint64_t *out);
 
+/* The relation generators of the reference's mc/ comparison code (mc/src/generator.c), serial forms, same glibc
+ * rand() stream after srand(seed) (seed_generator, :56-61; mc/src/main.c:337-338 seeds R with 12345, S with 54321),
+ * written as 8-byte tuples {key, payload = 0}:
+ *   "pk"          create_relation_pk (:241-261): keys 1..n, Knuth shuffle (:83-93)
+ *   "pk_lshuffle" create_relation_pk_lshuffle (:263-284): keys 1..n, lshuffle(window) (:96-110)
+ *   "fk"          create_relation_fk (:408-445): foreign keys into 1..maxid: n / maxid shuffled copies of 1..maxid,
+ *                 then a shuffled 1..(n % maxid)  -- workload A/B of mc/src/main.c:171-215
+ *   "nonunique"   create_relation_nonunique (:494-509): key = RAND_RANGE(maxid), 0 .. maxid-1. Key 0 is the table
+ *                 paths' empty marker (HJ_ERR_KEY_RANGE there); HJ_ALGO_PRJ takes it
+ *   "zipf"        create_relation_zipf (:521-538): gen_zipf(n, maxid, theta) of mc/src/genzipf.c
+ * Returns HJ_ERR_INVALID for an unknown kind or arguments the reference would divide by zero on. */
+int hj_generate_relation(const char *kind, uint64_t n, uint64_t maxid, int window, double theta,
+                         unsigned seed, uint64_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -360,6 +360,55 @@ int orc_build_probe_mt(const uint64_t *R, uint64_t rSize,
 }
 
 /* ------------------------------------------------------------------------ */
+/* mc/src/generator.c                                                          */
+/* ------------------------------------------------------------------------ */
+#define ORC_RAND_RANGE(N) ((double)rand() / ((double)RAND_MAX + 1) * (N))     /* generator.c:20 */
+
+static void orc_knuth_shuffle(uint64_t *t, uint64_t n)                       /* :83-93 */
+{
+    for (int64_t i = (int64_t)n - 1; i > 0; i--) {
+        int32_t j = (int32_t)ORC_RAND_RANGE(i);
+        uint64_t tmp = t[i]; t[i] = t[j]; t[j] = tmp;
+    }
+}
+
+static void orc_random_unique_gen(uint64_t *t, uint64_t n)                   /* :125-136 */
+{
+    for (uint64_t i = 0; i < n; i++) t[i] = i + 1;
+    orc_knuth_shuffle(t, n);
+}
+
+int orc_generate_relation(const char *kind, uint64_t n, uint64_t maxid, int window, double theta,
+                          unsigned seed, uint64_t *out)
+{
+    if (strcmp(kind, "zipf") == 0) return orc_generate_zipf(n, (uint32_t)maxid, theta, seed, out);   /* :521-538 */
+    srand(seed);                                                             /* seed_generator, :56-61 */
+    if (strcmp(kind, "pk") == 0) {
+        orc_random_unique_gen(out, n);
+    } else if (strcmp(kind, "pk_lshuffle") == 0) {                           /* :138-151, lshuffle :96-110 */
+        if (window <= 0) return -1;
+        for (uint64_t i = 0; i < n; i++) out[i] = i + 1;
+        for (uint64_t i = 0; i < n; i++) {
+            int32_t runway = (int32_t)(n - i);
+            int32_t mod = runway > window ? window : runway;
+            int32_t swap = rand() % mod;
+            uint64_t j = i + (uint64_t)swap;
+            uint64_t tmp = out[i]; out[i] = out[j]; out[j] = tmp;
+        }
+    } else if (strcmp(kind, "fk") == 0) {                                    /* :408-445 */
+        if (maxid == 0) return -1;
+        uint64_t iters = n / maxid, rem = n % maxid;
+        for (uint64_t i = 0; i < iters; i++) orc_random_unique_gen(out + maxid * i, maxid);
+        if (rem > 0) orc_random_unique_gen(out + maxid * iters, rem);
+    } else if (strcmp(kind, "nonunique") == 0) {                             /* :494-509, random_gen :230-238 */
+        for (uint64_t i = 0; i < n; i++) out[i] = (uint64_t)(int32_t)ORC_RAND_RANGE((int32_t)maxid);
+    } else {
+        return -1;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
 /* HTM bucketised table, sequential order (HTMHashBuild.hpp)                  */
 /* ------------------------------------------------------------------------ */
 static uint32_t next_pow2_u32(uint32_t v)

@@ -55,6 +55,19 @@ int orc_generate_data(const char *dist, uint64_t n, uint64_t distinct,
 int orc_generate_zipf(uint64_t n, uint32_t alphabet, double theta,
                       unsigned seed, uint64_t *out);
 
+/* mc's relation generators (mc/src/generator.c), serial forms, driven by libc rand() after srand(seed) exactly as
+ * seed_generator does (:56-61); mc seeds R with 12345 and S with 54321 (mc/src/main.c:337-338). Values are written
+ * as 8-byte tuples {key, payload = 0}. kind:
+ *   "pk"          create_relation_pk (:241-261): keys 1..n, knuth_shuffle (:83-93, j = RAND_RANGE(i), :20)
+ *   "pk_lshuffle" create_relation_pk_lshuffle (:263-284): keys 1..n, lshuffle(window) (:96-110)
+ *   "fk"          create_relation_fk (:408-445): n / maxid blocks of 1..maxid, each knuth-shuffled, then a block of
+ *                 1..(n % maxid)
+ *   "nonunique"   create_relation_nonunique (:494-509): key = RAND_RANGE(maxid), i.e. 0 .. maxid-1 (0 INCLUDED)
+ *   "zipf"        create_relation_zipf (:521-538) = gen_zipf(n, maxid, theta)
+ * Returns -1 for an unknown kind. */
+int orc_generate_relation(const char *kind, uint64_t n, uint64_t maxid, int window, double theta,
+                          unsigned seed, uint64_t *out);
+
 /* ---- nocc / atomic build + probe (sequential order) ---------------------- */
 
 typedef struct {

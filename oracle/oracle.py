@@ -23,6 +23,7 @@ def _load():
     lib = C.CDLL(_SO)
     lib.orc_generate_data.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
     lib.orc_generate_zipf.argtypes = [C.c_uint64, C.c_uint32, C.c_double, C.c_uint, C.c_void_p]
+    lib.orc_generate_relation.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_int, C.c_double, C.c_uint, C.c_void_p]
     lib.orc_build_probe_seq.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32,
                                         C.POINTER(OrcResult), C.c_void_p]
     lib.orc_build_probe_seq_ts.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64,
@@ -83,6 +84,15 @@ def generate_data(dist, n, distinct=None, window=16):
 def generate_zipf(n, alphabet, theta, seed):
     out = np.empty(n, dtype=np.uint64)
     _lib.orc_generate_zipf(n, alphabet, theta, seed, out.ctypes.data)
+    return out
+
+
+def generate_relation(kind, n, maxid=None, window=0, theta=0.0, seed=12345):
+    """mc/src/generator.c relations: kind in pk, pk_lshuffle, fk, nonunique, zipf (orc_generate_relation)."""
+    out = np.empty(n, dtype=np.uint64)
+    rc = _lib.orc_generate_relation(kind.encode(), n, n if maxid is None else maxid, window, theta, seed, out.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"unknown relation kind {kind}")
     return out
 
 

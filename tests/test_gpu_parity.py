@@ -312,6 +312,30 @@ def test_htm_log_pins_at_2p27(ctx):
     assert got["totalMatches"] == int(per.sum()) == n                            # S = 1..N, keys in [1, N]: every R tuple matches once
 
 
+def test_mc_workloads_true_cardinality_on_both_join_paths(ctx, golden_dir):
+    """The workloads of mc/src/main.c:343-408 (pk x fk with |S| != |R|, --non-unique, --skew, --local-shuffle-range) from
+    hj_generate_relation, joined on the GPU: the radix join and the bucketised table join (the correct-join mode of the
+    table path: dropped tuples live in overflow chains the probe also walks) must both give the TRUE cardinality the
+    reference's own NPO printed for the same command line (tests/golden/mc_workloads.json)."""
+    rows = json.load(open(os.path.join(golden_dir, "mc_workloads.json")))["rows"]
+    for row in rows:
+        skew = next((float(f.split("=")[1]) for f in row["flags"] if f.startswith("--skew=")), 0.0)
+        win = next((int(f.split("=")[1]) for f in row["flags"] if f.startswith("--local-shuffle-range=")), 0)
+        R = hj.generate_relation(row["rKind"], row["rSize"], row["rSize"], win, 0.0, row["rSeed"])
+        S = hj.generate_relation(row["sKind"], row["sSize"], row["rSize"], 0, skew, row["sSeed"])
+        got = ctx.run("prj", R, S)                              # takes key 0 (mc's nonunique keys are 0 .. maxid-1)
+        assert got["totalMatches"] == row["results"], ("prj", row)
+        if "--non-unique" in row["flags"]:                      # key 0 is the table paths' empty marker: shift the key domain
+            with pytest.raises(hj.HashJoinError) as e:
+                ctx.run("htm", R, S)
+            assert e.value.status == _lib.HJ_ERR_KEY_RANGE
+            R, S = R + np.uint64(1), S + np.uint64(1)
+        for variant in (1, 3):
+            got = ctx.run("htm", R, S, buildVariant=variant)
+            assert got["totalMatches"] == row["results"], ("htm", variant, row)
+            assert got["outputSum"] == got["inputSum"] == int(R.sum())
+
+
 # ---- PRJ ---------------------------------------------------------------------
 @pytest.mark.parametrize("dist,window", [("uniform", 16), ("random", 16), ("shuffle", 16), ("local_shuffle", 1024)])
 @pytest.mark.parametrize("n,bits", [(1 << 10, 4), (1 << 16, 14), (1 << 20, 14), (1 << 20, 9), (1 << 20, 16)])

@@ -275,3 +275,36 @@ def test_zipf_reference_binary_still_agrees_with_the_fixture(golden_dir):
         out = subprocess.run([exe, str(row["stream_size"]), str(row["alphabet_size"]), repr(row["theta"]), str(row["seed"]), "32"],
                              capture_output=True, text=True, check=True).stdout
         assert json.loads(out) == row
+
+
+# ---- mc's relation generators, pinned by the reference binary's true join cardinalities -------------------------------
+def _mc_relations(row, gen):
+    skew = next((float(f.split("=")[1]) for f in row["flags"] if f.startswith("--skew=")), 0.0)
+    win = next((int(f.split("=")[1]) for f in row["flags"] if f.startswith("--local-shuffle-range=")), 0)
+    R = gen(row["rKind"], row["rSize"], row["rSize"], win, 0.0, row["rSeed"])
+    S = gen(row["sKind"], row["sSize"], row["rSize"], 0, skew, row["sSeed"])        # maxid of S = |R| (mc/src/main.c:391-407)
+    return R, S
+
+
+def test_mc_generators_reproduce_the_reference_binarys_cardinalities(golden_dir):
+    """orc_generate_relation (libc rand(), as mc/src/generator.c) feeds a reference-free exact count; it must equal what
+    the reference's own NPO printed for the same command line (tests/golden/mc_workloads.json). For --non-unique the
+    count depends on every key of both streams."""
+    for row in _load(golden_dir, "mc_workloads.json")["rows"]:
+        R, S = _mc_relations(row, oracle.generate_relation)
+        assert oracle.true_cardinality(R, S) == row["results"], row
+        if row["rKind"].startswith("pk"):
+            assert np.array_equal(np.sort(R), np.arange(1, row["rSize"] + 1, dtype=np.uint64))
+        if "--non-unique" in row["flags"]:
+            assert int(R.min()) == 0 and int(R.max()) < row["rSize"]                 # RAND_RANGE(maxid): 0 included
+
+
+def test_mc_generators_product_equals_libc_restatement(golden_dir):
+    """hj_generate_relation (the product's own glibc TYPE_3 stream) element for element against the libc-driven one."""
+    import htm_hashjoin_amd as hj
+    for row in _load(golden_dir, "mc_workloads.json")["rows"]:
+        R, S = _mc_relations(row, oracle.generate_relation)
+        Rp, Sp = _mc_relations(row, hj.generate_relation)
+        assert np.array_equal(R, Rp) and np.array_equal(S, Sp), row
+    with pytest.raises(hj.HashJoinError):
+        hj.generate_relation("no_such_kind", 10)
