@@ -5,12 +5,14 @@
 
 #include "../../include/htm_hashjoin.h"
 #include "hj_device.h"
+#include "hj_rand.h"
 
 #include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 using namespace hj;
 
@@ -46,6 +48,11 @@ struct hj_ctx {
     unsigned int* htmOvfCount = nullptr; uint32_t* htmOvfBase = nullptr; uint32_t* htmScan = nullptr; uint64_t capHtmBuckets = 0;
     uint64_t* htmOverflow = nullptr; uint64_t capHtmOverflow = 0;       // overflow buckets (index 0 unused)
     uint64_t htmOverflowUsed = 0;
+    // streaming Zipf generator (hj_zipf_open / hj_zipf_next_dev)
+    hjhost::GlibcRand* zipfRng = nullptr;
+    double* zipfLut = nullptr; uint32_t* zipfAlphabet = nullptr; uint32_t zipfAlphabetSize = 0;   // device
+    int* zipfRawHost[2] = {nullptr, nullptr}; int* zipfRawDev[2] = {nullptr, nullptr}; uint64_t zipfRawCap = 0;
+    hipEvent_t zipfDone[2] = {nullptr, nullptr}; int zipfFlip = 0;
     uint32_t variantUsed = 1;
     // counters
     Counters* dCtr = nullptr;
@@ -189,10 +196,27 @@ int hj_create(int device, hj_ctx** out) { return create_common(device, nullptr, 
 
 int hj_create_on_stream(int device, void* hip_stream, hj_ctx** out) { return create_common(device, hip_stream, false, out); }
 
+static void zipf_release(hj_ctx* c)
+{
+    delete c->zipfRng; c->zipfRng = nullptr;
+    if (c->zipfLut) hipFree(c->zipfLut);
+    if (c->zipfAlphabet) hipFree(c->zipfAlphabet);
+    c->zipfLut = nullptr; c->zipfAlphabet = nullptr; c->zipfAlphabetSize = 0;
+    for (int i = 0; i < 2; ++i) {
+        if (c->zipfRawHost[i]) hipHostFree(c->zipfRawHost[i]);
+        if (c->zipfRawDev[i]) hipFree(c->zipfRawDev[i]);
+        if (c->zipfDone[i]) hipEventDestroy(c->zipfDone[i]);
+        c->zipfRawHost[i] = nullptr; c->zipfRawDev[i] = nullptr; c->zipfDone[i] = nullptr;
+    }
+    c->zipfRawCap = 0;
+}
+
 void hj_destroy(hj_ctx* c)
 {
     if (!c) return;
     hipSetDevice(c->device);
+    if (c->stream || !c->ownStream) hipStreamSynchronize(c->stream);
+    zipf_release(c);
     if (c->stream || !c->ownStream) hipStreamSynchronize(c->stream);
     void* frees[] = {c->table, c->dCtr, c->tmpA, c->partR, c->partS, c->work, c->stageR, c->stageS,
                      c->ownerBuf, c->queueBuf, c->queueCount, c->fitCount, c->boundsBuf, c->htmConflicts, c->htmOvfCount,
@@ -711,6 +735,67 @@ int hj_prj_workspace_info(uint64_t rSize, uint64_t sSize, uint32_t radixBits, ui
     const PrjPlan pl = prj_plan(rSize, sSize, bits);
     out[0] = pl.workspaceBytes; out[1] = pl.histEntries;
     out[2] = prj_hist_entries_needed(rSize, bits); out[3] = prj_hist_entries_needed(sSize, bits);
+    return HJ_OK;
+}
+
+// ---- streaming Zipf generator ---------------------------------------------------
+int hj_zipf_open(hj_ctx* c, uint64_t alphabetSize, double theta, unsigned seed)
+{
+    if (!c) return HJ_ERR_INVALID;
+    if (alphabetSize == 0 || alphabetSize > 0xFFFFFFFFull || !(theta >= 0.0)) return fail(c, HJ_ERR_INVALID, "hj_zipf_open: alphabet in [1, 2^32), theta >= 0");
+    HJ_HIP(c, hipSetDevice(c->device));
+    HJ_HIP(c, hipStreamSynchronize(c->stream));
+    zipf_release(c);
+    c->zipfRng = new (std::nothrow) hjhost::GlibcRand(seed);
+    if (!c->zipfRng) return HJ_ERR_OOM;
+    std::vector<uint32_t> alphabet;
+    std::vector<double> lut;
+    hjhost::zipf_tables(*c->zipfRng, (uint32_t)alphabetSize, theta, alphabet, lut);       // consumes alphabetSize - 1 draws
+    HJ_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->zipfLut), alphabetSize * sizeof(double)));
+    HJ_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->zipfAlphabet), alphabetSize * sizeof(uint32_t)));
+    HJ_HIP(c, hipMemcpy(c->zipfLut, lut.data(), alphabetSize * sizeof(double), hipMemcpyHostToDevice));
+    HJ_HIP(c, hipMemcpy(c->zipfAlphabet, alphabet.data(), alphabetSize * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->zipfAlphabetSize = (uint32_t)alphabetSize;
+    for (int i = 0; i < 2; ++i) HJ_HIP(c, hipEventCreateWithFlags(&c->zipfDone[i], hipEventDisableTiming));
+    return HJ_OK;
+}
+
+int hj_zipf_next_dev(hj_ctx* c, uint64_t n, uint64_t* dOut)
+{
+    if (!c || (!dOut && n)) return HJ_ERR_INVALID;
+    if (!c->zipfRng) return fail(c, HJ_ERR_STATE, "hj_zipf_next_dev: hj_zipf_open() first");
+    HJ_HIP(c, hipSetDevice(c->device));
+    // pieces of at most 2^26 draws through two pinned buffers: the host draws piece k + 1 of the serial rand() stream
+    // while the device still copies and searches piece k
+    const uint64_t piece = 1ull << 26;
+    if (c->zipfRawCap == 0) {
+        for (int i = 0; i < 2; ++i) {
+            HJ_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->zipfRawHost[i]), piece * sizeof(int)));
+            HJ_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->zipfRawDev[i]), piece * sizeof(int)));
+        }
+        c->zipfRawCap = piece;
+    }
+    for (uint64_t off = 0; off < n; off += piece) {
+        const uint64_t m = n - off < piece ? n - off : piece;
+        const int b = c->zipfFlip;
+        c->zipfFlip ^= 1;
+        HJ_HIP(c, hipEventSynchronize(c->zipfDone[b]));          // the previous use of this buffer pair has been consumed
+        int* h = c->zipfRawHost[b];
+        for (uint64_t i = 0; i < m; ++i) h[i] = c->zipfRng->next();
+        HJ_HIP(c, hipMemcpyAsync(c->zipfRawDev[b], h, m * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        launch_zipf_lookup(c->zipfRawDev[b], m, c->zipfLut, c->zipfAlphabet, c->zipfAlphabetSize, dOut + off, c->stream);
+        HJ_HIP(c, hipGetLastError());
+        HJ_HIP(c, hipEventRecord(c->zipfDone[b], c->stream));
+    }
+    return HJ_OK;
+}
+
+int hj_zipf_close(hj_ctx* c)
+{
+    if (!c) return HJ_ERR_INVALID;
+    HJ_HIP(c, hipSetDevice(c->device));
+    HJ_HIP(c, hipStreamSynchronize(c->stream));
+    zipf_release(c);
     return HJ_OK;
 }
 

@@ -2,14 +2,12 @@
 // of generate_data() in the reference's include/DataGen.hpp:26-122.
 //
 // The reference draws from libc rand() after srand(0), so its inputs (and the
-// inputSum values in its logs) are a function of glibc's generator. To stay
-// bit-identical without going through libc's locked global state, GlibcRand
-// below restates that generator (glibc stdlib/random_r.c, TYPE_3: the additive
-// feedback r[i] = r[i-3] + r[i-31] over 31 words, seeded by the Lehmer LCG
-// 16807 mod 2^31-1, first 310 outputs discarded, result = r >> 1).
-// tests/test_datagen.py checks it against libc rand() itself.
+// inputSum values in its logs) are a function of glibc's generator: hj_rand.h
+// restates that generator (GlibcRand); tests/test_datagen.py checks it against
+// libc rand() itself.
 
 #include "../../include/htm_hashjoin.h"
+#include "hj_rand.h"
 
 #include <algorithm>
 #include <cmath>
@@ -19,38 +17,8 @@
 
 namespace {
 
-class GlibcRand {
-  public:
-    explicit GlibcRand(unsigned seed) { reseed(seed); }
-    void reseed(unsigned seed)
-    {
-        if (seed == 0) seed = 1;
-        int32_t word = (int32_t)seed;
-        st_[0] = (uint32_t)word;
-        for (int i = 1; i < 31; ++i) {
-            const long hi = word / 127773, lo = word % 127773;
-            long w = 16807 * lo - 2836 * hi;
-            if (w < 0) w += 2147483647;
-            word = (int32_t)w;
-            st_[i] = (uint32_t)word;
-        }
-        f_ = 3; r_ = 0;
-        for (int k = 0; k < 310; ++k) (void)next();
-    }
-    inline int next()
-    {
-        const uint32_t v = (st_[f_] += st_[r_]);
-        if (++f_ >= 31) f_ = 0;
-        if (++r_ >= 31) r_ = 0;
-        return (int)(v >> 1);
-    }
-
-  private:
-    uint32_t st_[31];
-    int f_, r_;
-};
-
-constexpr int kRandMax = 2147483647;
+using hjhost::GlibcRand;
+using hjhost::kRandMax;
 
 // Parallel LSD radix sort of values < 2^32 (11 bits x 3 passes). Any correct sort
 // gives std::sort's result on plain integers (DataGen.hpp:43,60).
@@ -123,29 +91,11 @@ int gen_zipf(GlibcRand& rng, uint64_t n, uint64_t distinct, double zipfTheta, ui
 {
     if (distinct == 0 || distinct > 0xFFFFFFFFull || !(zipfTheta >= 0.0)) return HJ_ERR_INVALID;
     const uint32_t asz = (uint32_t)distinct;
-    std::vector<uint32_t> alphabet(asz);
-    for (uint32_t i = 0; i < asz; ++i) alphabet[i] = i + 1;
-    for (uint32_t i = asz - 1; i > 0; --i) {
-        const unsigned k = (unsigned)((unsigned long)i * (unsigned long)rng.next() / kRandMax);
-        std::swap(alphabet[i], alphabet[k]);
-    }
-    std::vector<double> lut(asz);
-    double scaling = 0.0, sum = 0.0;
-    for (uint32_t i = 1; i <= asz; ++i) scaling += 1.0 / std::pow((double)i, zipfTheta);
-    for (uint32_t i = 1; i <= asz; ++i) { sum += 1.0 / std::pow((double)i, zipfTheta); lut[i - 1] = sum / scaling; }
-    for (uint64_t i = 0; i < n; ++i) {
-        const double r = ((double)rng.next()) / kRandMax;
-        unsigned left = 0, right = asz - 1, pos;
-        if (lut[0] >= r) pos = 0;
-        else {
-            while (right - left > 1) {
-                const unsigned m = (left + right) / 2;
-                if (lut[m] < r) left = m; else right = m;
-            }
-            pos = right;
-        }
-        out[i] = alphabet[pos];
-    }
+    std::vector<uint32_t> alphabet;
+    std::vector<double> lut;
+    hjhost::zipf_tables(rng, asz, zipfTheta, alphabet, lut);
+    for (uint64_t i = 0; i < n; ++i)
+        out[i] = alphabet[hjhost::zipf_position(lut.data(), asz, ((double)rng.next()) / kRandMax)];
     return HJ_OK;
 }
 

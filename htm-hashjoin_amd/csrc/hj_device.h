@@ -91,6 +91,8 @@ void launch_build_atomic_min(const void* R, bool key32, uint64_t n, uint64_t* ta
 void launch_probe(const void* S, bool key32, uint64_t n, const uint64_t* table, uint64_t tableSize, uint32_t hshift,
                   uint32_t probeLen, ShardCheck sc, Counters* ctr, hipStream_t s);
 void launch_table_sums(const uint64_t* table, uint64_t tableSize, uint64_t halfSlots, Counters* ctr, hipStream_t s);
+void launch_zipf_lookup(const int* raw, uint64_t n, const double* lut, const uint32_t* alphabet, uint32_t alphabetSize,
+                        uint64_t* out, hipStream_t s);
 // Marks the whole table valid (variant 1 clears and may touch all of it).
 void launch_set_full_range(uint64_t tableSize, Counters* ctr, Gate gate, hipStream_t s);
 // multi-GPU destination split (defined in hj_prj.hip: one order-preserving radix pass, tuples in, keys out);

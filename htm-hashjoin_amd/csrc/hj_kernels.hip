@@ -319,6 +319,35 @@ void launch_table_sums(const uint64_t* table, uint64_t tableSize, uint64_t halfS
                        table, tableSize, halfSlots, ctr);
 }
 
+// ---------------------------------------------------------------------------
+// Zipf draws on the device (hj_zipf_next_dev): the binary search of gen_zipf (mc/src/genzipf.c:118-151) for n raw
+// rand() values against the cumulative table; the host only produces the serial rand() stream.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_zipf_lookup(const int* __restrict__ raw, uint64_t n, const double* __restrict__ lut, const uint32_t* __restrict__ alphabet,
+              uint32_t alphabetSize, uint64_t* __restrict__ out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+        const double r = ((double)raw[i]) / 2147483647.0;      // (double) rand() / RAND_MAX
+        uint32_t pos = 0;
+        if (!(lut[0] >= r)) {
+            uint32_t left = 0, right = alphabetSize - 1;
+            while (right - left > 1) {
+                const uint32_t m = (left + right) / 2;
+                if (lut[m] < r) left = m; else right = m;
+            }
+            pos = right;
+        }
+        out[i] = alphabet[pos];
+    }
+}
+
+void launch_zipf_lookup(const int* raw, uint64_t n, const double* lut, const uint32_t* alphabet, uint32_t alphabetSize,
+                        uint64_t* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_zipf_lookup, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, raw, n, lut, alphabet, alphabetSize, out);
+}
+
 __global__ void k_set_full_range(uint64_t tableSize, Counters* __restrict__ ctr, Gate gate)
 {
     if (gate_closed(gate)) return;

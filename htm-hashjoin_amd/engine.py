@@ -182,6 +182,17 @@ class HashJoinContext:
     def copy_d2h(self, dst_np, src_ptr):
         self._check(lib.hj_copy_d2h(self._h, dst_np.ctypes.data, C.c_void_p(src_ptr), dst_np.nbytes))
 
+    # ---- streaming Zipf generator (probe sides that do not fit one host buffer) -------------------------------
+    def zipf_open(self, alphabet_size, theta, seed=0):
+        self._check(lib.hj_zipf_open(self._h, alphabet_size, float(theta), int(seed)))
+
+    def zipf_next(self, n, d_out):
+        """the next n draws of the stream, as 8-byte tuples at device pointer d_out"""
+        self._check(lib.hj_zipf_next_dev(self._h, n, C.c_void_p(d_out)))
+
+    def zipf_close(self):
+        self._check(lib.hj_zipf_close(self._h))
+
     def shard_histogram(self, d_in, n, n_shards, d_counts, mode=0):
         """mode = bit position of the radix digit (0 = low key bits), | SHARD_ONE_BASED for (key - 1)"""
         self._check(lib.hj_shard_histogram_dev(self._h, C.c_void_p(d_in), n, n_shards, mode, C.c_void_p(d_counts)))

@@ -264,6 +264,17 @@ int hj_copy_d2h(hj_ctx *ctx, void *dst_host, const void *src_dev, uint64_t bytes
 int hj_generate_data(const char *dist, uint64_t n, uint64_t distinct, int window,
                      double zipfTheta, uint64_t *out);
 
+/* Streaming Zipf generator for probe sides too large to generate and copy in one piece (BASELINE config 5:
+ * |S| = 4 * 10^9 draws over 2^28 keys). hj_zipf_open builds gen_zipf's alphabet permutation and cumulative table
+ * (mc/src/genzipf.c:28-93) after srand(seed) and keeps them on the device; every hj_zipf_next_dev(n) continues the SAME
+ * rand() stream where the last call stopped and writes the next n draws to dOut as 8-byte tuples: the host produces
+ * only the serial rand() values, the binary search of genzipf.c:118-151 runs on the GPU. The concatenation of the
+ * slices equals hj_generate_relation("zipf", total, alphabet, 0, theta, seed, ...) element for element (seed 0:
+ * hj_generate_data("zipf")). Asynchronous on the context's stream apart from the host's own drawing. */
+int hj_zipf_open(hj_ctx *ctx, uint64_t alphabetSize, double theta, unsigned seed);
+int hj_zipf_next_dev(hj_ctx *ctx, uint64_t n, uint64_t *dOut);
+int hj_zipf_close(hj_ctx *ctx);
+
 /* The relation generators of the reference's mc/ comparison code (mc/src/generator.c), serial forms, same glibc
  * rand() stream after srand(seed) (seed_generator, :56-61; mc/src/main.c:337-338 seeds R with 12345, S with 54321),
  * written as 8-byte tuples {key, payload = 0}:

@@ -84,3 +84,39 @@ def test_config3_prj_local_shuffle_1024_closed_forms():
             r = c2.fetch()
         assert (r["conflicts"], r["totalMatches"], r["inputSum"], r["tableSumFull"]) == (0, N, 576460752840294400, 576460752840294400)
         c.dev_free(dR); c.dev_free(dS)
+
+
+def test_config5_skew_stress_full_size():
+    """BASELINE configs[4]: |R| = 2^28 unique keys, |S| = 2^32 (> 4 * 10^9) DISTINCT Zipf(0.9) draws over R's key domain,
+    streamed in 16 slices of 2^28 (hj_zipf_next_dev: the serial rand() stream on the host, the LUT search on the GPU).
+    R holds every key of the domain exactly once, so every probe finds exactly its one partner: totalMatches = |S|, on
+    the open-addressing table and on the bucketised one. A slice is also copied back and compared with the host
+    generator's first 2^20 draws."""
+    n, slices, per = 1 << 28, 16, 1 << 28
+    R = hj.generate_data("local_shuffle", n, n, 1024)
+    with hj.HashJoinContext(0) as c, hj.HashJoinContext(0) as h:
+        dR = c.dev_alloc(n * 8); c.copy_h2d(dR, R)
+        del R
+        dS = c.dev_alloc(per * 8)
+        c.reserve("atomic", n, per)
+        c.build(dR, n)
+        h.reserve("htm", n, per)
+        h.build(dR, n)
+        c.zipf_open(n, 0.9, 0)
+        for k in range(slices):
+            c.zipf_next(per, dS)
+            c.probe(dS, per)
+            c.synchronize()                        # dS is reused; h runs on its own stream
+            h.probe(dS, per)
+            h.synchronize()
+            if k == 0:
+                head = np.empty(1 << 20, dtype=np.uint64)
+                c.copy_d2h(head, dS)
+        c.zipf_close()
+        r, rh = c.fetch(), h.fetch()
+        c.dev_free(dR); c.dev_free(dS)
+    assert (r["conflicts"], r["sSize"], r["totalMatches"]) == (0, slices * per, slices * per)
+    assert (rh["conflicts"], rh["totalMatches"]) == (0, slices * per)
+    assert slices * per >= 4_000_000_000
+    # the stream's head against the one-piece host generator at a smaller total (same seed, same alphabet: same prefix)
+    assert np.array_equal(head[:4096], hj.generate_data("zipf", 4096, n, 16, zipf_theta=0.9))

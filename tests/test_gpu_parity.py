@@ -820,6 +820,31 @@ def test_skew_probe_side_zipf(ctx):
     assert got["totalMatches"] == S.size
 
 
+def test_streaming_zipf_equals_the_host_generator():
+    """hj_zipf_open / hj_zipf_next_dev: the device-side binary search over the host's rand() stream, in slices of odd
+    lengths, gives element for element what hj_generate_data("zipf") (seed 0) and hj_generate_relation("zipf", seed)
+    give in one piece -- which tests/test_oracle_golden.py pins to the reference's own gen_zipf."""
+    for alphabet, theta, seed, slices in ((1 << 16, 0.9, 0, (1000, 1, 65536 + 7, 12345)), (1000, 1.05, 54321, (70000, 5)),
+                                          (1, 0.9, 0, (10,)), (1 << 18, 0.0, 12345, (1 << 17, 3))):
+        total = sum(slices)
+        want = (hj.generate_data("zipf", total, alphabet, 16, zipf_theta=theta) if seed == 0 else
+                hj.generate_relation("zipf", total, alphabet, 0, theta, seed))
+        with hj.HashJoinContext(0) as c:
+            d = c.dev_alloc(total * 8)
+            c.zipf_open(alphabet, theta, seed)
+            off = 0
+            for m in slices:
+                c.zipf_next(m, d + 8 * off)
+                off += m
+            got = np.empty(total, dtype=np.uint64)
+            c.copy_d2h(got, d)
+            c.zipf_close()
+            with pytest.raises(hj.HashJoinError):
+                c.zipf_next(1, d)
+            c.dev_free(d)
+        assert np.array_equal(got, want), (alphabet, theta, seed)
+
+
 def test_main_cli_on_gpu():
     """The reference's command line end to end on the GPU: `main --algo atomic|htm|prj` prints the reference's
     JSON fields (NoCCHashBuild.hpp:127-146 order) with the pinned sequential-order values."""

@@ -1,88 +1,165 @@
 #!/usr/bin/env python3
-"""The reference's shuffle-window sweep (experiments/probe.sh, motivation.sh: local_shuffle, rSize = 2^27,
-W = 2^0 .. 2^27) on the MI355X engine: open-addressing build+probe (auto variant) and PRJ per W, one JSON line
-each, in the reference's field order plus the device timings. Optional CPU leg every 4th W: the product's own
-host-thread port of the reference loops (`main --algo cpu-atomic`, same flags as the reference). Usage: python tools/sweep.py [--log2n 27] [--reps 3] [--cpu] > profiles/rNN_sweep.jsonl"""
+"""The reference's shuffle-window sweep at the reference's protocol, on the MI355X engine with the CPU beside it.
+
+experiments/probe.sh and motivation.sh run, for W = 2^0 .. 2^27 at rSize = 2^27 with `local_shuffle`, the operators
+nocc, atomic, htm (transactionSize 16) and mc's PRO, one JSON line per run; experiments/runner.sh:3-43 repeats every
+script N = 5 times (figs/perf.png plots the result). This harness does the same sweep:
+
+    for every W:   GPU  atomic (open-addressing table), htm (bucketised table), prj (radix join), auto (adaptive)
+                   CPU  nocc and atomic: the product's host-thread port of the reference's loops (`main --algo nocc |
+                        cpu-atomic`, csrc/main.cpp) on this machine's cores -- at EVERY W, like the reference
+    N = 5 repeats each, the MEDIAN reported (`hashBuildTimeInMicroseconds`), all repeats kept in `runs_us`
+
+and emits the reference's JSON fields first and in its order, so a parser of the reference's logs reads these too.
+Every repeat's counters are ASSERTED against the pins the reference's own logs hold for this sweep (unique keys:
+conflicts 0, totalMatches = rSize, inputSum = N(N+1)/2, outputSum = the per-operator value of
+tests/golden/reference_logs.json; PRO's checksum in closed form), so a line that is printed is a line that is right.
+
+    python tools/sweep.py [--log2n 27] [--repeats 5] [--no-cpu] [--max-log2w K] > profiles/rNN_sweep.jsonl
+"""
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import htm_hashjoin_amd as hj
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+MAIN = os.path.join(ROOT, "htm-hashjoin_amd", "bin", "main")
+
+
+def expected(algo, n, radix_bits=None):
+    """What every run of the sweep must print (local_shuffle = unique keys 1..n): the reference's logged values
+    (experiments/new_backup/probe_log*, motivation_log*: tests/golden/reference_logs.json) as closed forms in n."""
+    tri = n * (n + 1) // 2
+    if algo == "nocc":                          # NoCCHashBuild.hpp:94 sums table[0..rSize) only: key n sits in slot n
+        return {"conflicts": 0, "totalMatches": n, "inputSum": tri, "outputSum": tri - n}
+    if algo in ("atomic", "auto-table"):
+        return {"conflicts": 0, "totalMatches": n, "inputSum": tri, "outputSum": tri}
+    if algo == "htm":
+        return {"conflictCount": 0, "totalMatches": n, "inputSum": tri, "outputSum": tri}
+    if algo in ("prj", "auto-prj"):             # fork's PRO "Results" = sum of (k >> bits) & (nextpow2(n / 2^bits) - 1)
+        per = max(n >> radix_bits, 1)
+        mask = (1 << (per - 1).bit_length()) - 1 if per > 1 else 0
+        total = 0
+        for v in range((n >> radix_bits) + 1):
+            lo, hi = max(v << radix_bits, 1), min(((v + 1) << radix_bits) - 1, n)
+            if hi >= lo:
+                total += (v & mask) * (hi - lo + 1)
+        return {"totalMatches": n, "results": total}
+    raise ValueError(algo)
+
+
+def check(line, want):
+    for k, v in want.items():
+        if line[k] != v:
+            raise AssertionError(f"sweep pin violated: {k} = {line[k]}, expected {v}: {line}")
+
+
+def summarise(runs_us):
+    return {"hashBuildTimeInMicroseconds": int(statistics.median(runs_us)), "repeats": len(runs_us),
+            "runs_us": [int(x) for x in runs_us]}
+
+
+def cpu_lines(algo, n, window, repeats):
+    """`main --algo nocc|cpu-atomic --repeat N`: the reference's own loops on host threads (one data generation)."""
+    out = subprocess.run([MAIN, "--algo", algo, "--rSize", str(n), "--probeLength", "4", "--dataDistr", "local_shuffle",
+                          "--shuffleRange", str(window), "--repeat", str(repeats)], capture_output=True, text=True, check=True).stdout
+    return [json.loads(l) for l in out.splitlines() if l.startswith("{")]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log2n", type=int, default=27)
-    ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--cpu", action="store_true")
-    ap.add_argument("--prj", action="store_true")
-    ap.add_argument("--auto", action="store_true", help="also run HJ_ALGO_AUTO (locality sample -> table or radix join)")
+    ap.add_argument("--repeats", type=int, default=5, help="experiments/runner.sh: N=5")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--max-log2w", type=int, default=None, help="stop the window sweep early (default: up to rSize)")
     a = ap.parse_args()
+    import htm_hashjoin_amd as hj
     n = 1 << a.log2n
+    top = a.log2n if a.max_log2w is None else min(a.max_log2w, a.log2n)
     S = hj.generate_data("sorted", n)
-    with hj.HashJoinContext(0) as ctx, hj.HashJoinContext(0) as pctx, hj.HashJoinContext(0) as actx:
+    with hj.HashJoinContext(0) as ctx, hj.HashJoinContext(0) as hctx, hj.HashJoinContext(0) as pctx, hj.HashJoinContext(0) as actx:
         dS = ctx.dev_alloc(n * 8)
         dR = ctx.dev_alloc(n * 8)
         ctx.copy_h2d(dS, S)
+        del S
         ctx.reserve("atomic", n, n)
-        if a.prj:
-            pctx.reserve("prj", n, n)
-        if a.auto:
-            actx.reserve("auto", n, n)
-        for e in range(0, a.log2n + 1):
+        hctx.reserve("htm", n, n)
+        pctx.reserve("prj", n, n)
+        actx.reserve("auto", n, n)
+        for e in range(0, top + 1):
             W = 1 << e
+            tag = {"dataDistr": "local_shuffle", "shuffleRange": W}
+            if not a.no_cpu:
+                for algo, name in (("nocc", "nocc"), ("cpu-atomic", "atomic")):
+                    rows = cpu_lines(algo, n, W, a.repeats)
+                    for r in rows:
+                        check(r, expected(name, n))
+                    line = {"algo": name, "rSize": n, "probeLength": 4,
+                            **summarise([r["hashBuildTimeInMicroseconds"] for r in rows]), "conflicts": 0, "totalMatches": n,
+                            "inputSum": rows[0]["inputSum"], "outputSum": rows[0]["outputSum"], **tag, "device": "cpu",
+                            "cpu_threads": rows[0]["cpu_threads"]}
+                    line["mtuples_per_s"] = 2 * n / max(line["hashBuildTimeInMicroseconds"], 1)
+                    print(json.dumps(line), flush=True)
             R = hj.generate_data("local_shuffle", n, n, W)
             ctx.copy_h2d(dR, R)
-            best = None
-            for _ in range(a.reps):
-                ctx.build(dR, n)
-                ctx.probe(dS, n)
-                ctx.checksums()
-                r = ctx.fetch()
-                if best is None or r["total_us"] < best["total_us"]:
-                    best = r
-            line = {"algo": "atomic", "rSize": n, "probeLength": 4,
-                    "hashBuildTimeInMicroseconds": int(best["total_us"] + best["clear_us"]), "conflicts": best["conflicts"],
-                    "totalMatches": best["totalMatches"], "inputSum": best["inputSum"], "outputSum": best["outputSum"],
-                    "dataDistr": "local_shuffle", "shuffleRange": W, "device": "hip", "buildVariant": best["buildVariant"],
-                    "buildDeferred": best["buildDeferred"], "clear_us": best["clear_us"], "build_us": best["build_us"],
-                    "probe_us": best["probe_us"], "mtuples_per_s": 2 * n / (best["total_us"] + best["clear_us"])}
+            del R
+            # ---- GPU: open-addressing table (NoCC / Atomic semantics, sequential-order result) ----
+            runs, last = [], None
+            for _ in range(a.repeats):
+                ctx.build(dR, n); ctx.probe(dS, n); ctx.checksums()
+                last = ctx.fetch()
+                check(last, expected("atomic", n))
+                runs.append(last["total_us"] + last["clear_us"])
+            line = {"algo": "atomic", "rSize": n, "probeLength": 4, **summarise(runs), "conflicts": last["conflicts"],
+                    "totalMatches": last["totalMatches"], "inputSum": last["inputSum"], "outputSum": last["outputSum"], **tag,
+                    "device": "hip", "buildVariant": last["buildVariant"], "buildDeferred": last["buildDeferred"],
+                    "build_us": last["build_us"], "probe_us": last["probe_us"]}
+            line["mtuples_per_s"] = 2 * n / max(line["hashBuildTimeInMicroseconds"], 1)
             print(json.dumps(line), flush=True)
-            if a.prj:
-                pb = None
-                for _ in range(a.reps):
-                    pctx.prj_join(dR, n, dS, n)
-                    r = pctx.fetch()
-                    if pb is None or r["total_us"] < pb["total_us"]:
-                        pb = r
-                print(json.dumps({"algo": "prj", "rSize": n, "hashBuildTimeInMicroseconds": int(pb["total_us"]),
-                                  "totalMatches": pb["totalMatches"], "results": pb["prjChecksum"], "radixBits": pb["radixBits"],
-                                  "dataDistr": "local_shuffle", "shuffleRange": W, "device": "hip",
-                                  "partition_us": pb["partition_us"], "join_us": pb["join_us"],
-                                  "mtuples_per_s": 2 * n / pb["total_us"]}), flush=True)
-            if a.auto:
-                ab = None
-                for _ in range(a.reps):
-                    actx.join(dR, n, dS, n)
-                    r = actx.fetch()
-                    t = r["total_us"] + r["clear_us"]
-                    if ab is None or t < ab[0]:
-                        ab = (t, r)
-                t, r = ab
-                print(json.dumps({"algo": "auto", "algoUsed": r["algoUsed"], "rSize": n, "hashBuildTimeInMicroseconds": int(t),
-                                  "totalMatches": r["totalMatches"], "dataDistr": "local_shuffle", "shuffleRange": W,
-                                  "device": "hip", "mtuples_per_s": 2 * n / t}), flush=True)
-            if a.cpu and e % 4 == 2:
-                import subprocess
-                main = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "htm-hashjoin_amd", "bin", "main")
-                out = subprocess.run([main, "--algo", "cpu-atomic", "--rSize", str(n), "--probeLength", "4", "--dataDistr",
-                                      "local_shuffle", "--shuffleRange", str(W)], capture_output=True, text=True).stdout
-                c = json.loads(out)
-                c.update(dataDistr="local_shuffle", shuffleRange=W,
-                         mtuples_per_s=2 * n / max(c["hashBuildTimeInMicroseconds"], 1))
-                print(json.dumps(c), flush=True)
+            # ---- GPU: bucketised table (HTMHashBuild semantics) ----
+            runs = []
+            for _ in range(a.repeats):
+                hctx.build(dR, n); hctx.probe(dS, n); hctx.checksums()
+                last = hctx.fetch()
+                check({"conflictCount": last["conflicts"], **last}, expected("htm", n))
+                runs.append(last["total_us"])
+            line = {"algo": "htm", "rSize": n, "transactionSize": 16, "probeLength": 4, **summarise(runs), "conflictCount": 0,
+                    "failedTransactions": 0, "totalMatches": last["totalMatches"], "inputSum": last["inputSum"],
+                    "outputSum": last["outputSum"], **tag, "device": "hip", "buildVariant": last["buildVariant"],
+                    "build_us": last["build_us"], "probe_us": last["probe_us"]}
+            line["mtuples_per_s"] = 2 * n / max(line["hashBuildTimeInMicroseconds"], 1)
+            print(json.dumps(line), flush=True)
+            # ---- GPU: radix join (mc PRO + the probe the fork disabled) ----
+            runs = []
+            for _ in range(a.repeats):
+                pctx.prj_join(dR, n, dS, n)
+                last = pctx.fetch()
+                check({"results": last["prjChecksum"], **last}, expected("prj", n, last["radixBits"]))
+                runs.append(last["total_us"])
+            line = {"algo": "prj", "rSize": n, **summarise(runs), "totalMatches": last["totalMatches"], "results": last["prjChecksum"],
+                    "radixBits": last["radixBits"], **tag, "device": "hip", "partition_us": last["partition_us"], "join_us": last["join_us"]}
+            line["mtuples_per_s"] = 2 * n / max(line["hashBuildTimeInMicroseconds"], 1)
+            print(json.dumps(line), flush=True)
+            # ---- GPU: adaptive (locality pre-round -> table join or radix join) ----
+            runs = []
+            for _ in range(a.repeats):
+                actx.join(dR, n, dS, n)
+                last = actx.fetch()
+                if last["algoUsed"] == "prj":
+                    check({"results": last["prjChecksum"], **last}, expected("auto-prj", n, last["radixBits"]))
+                else:
+                    actx.checksums()
+                    last = actx.fetch()
+                    check(last, expected("auto-table", n))
+                runs.append(last["total_us"] + last["clear_us"])
+            line = {"algo": "auto", "algoUsed": last["algoUsed"], "rSize": n, **summarise(runs), "totalMatches": last["totalMatches"],
+                    **tag, "device": "hip"}
+            line["mtuples_per_s"] = 2 * n / max(line["hashBuildTimeInMicroseconds"], 1)
+            print(json.dumps(line), flush=True)
         ctx.dev_free(dR)
         ctx.dev_free(dS)
 
