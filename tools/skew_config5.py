@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""BASELINE config 5: skew stress, |R| = 2^28 unique keys, |S| = 4 x 2^30 probes drawn Zipf(0.9) over R's key domain
-(mc/src/genzipf.c method; a 2^log2s-tuple sample is probed `reps` times: 2^28 x 16 = 4.29 G probes), 1 GPU. R unique => every probe
-finds exactly one tuple: totalMatches must equal the number of probes. One JSON line per algorithm.
-usage: python tools/skew_config5.py [--log2r 28] [--log2s 28] [--reps 16] [--rdist local_shuffle --window 1024]"""
+"""BASELINE configs[4] (skew stress) at full size: |R| = 2^28 unique keys (local_shuffle W=1024), |S| = 2^32 > 4 * 10^9
+DISTINCT Zipf(0.9) draws over R's key domain, streamed in 16 slices of 2^28 by hj_zipf_next_dev (the serial rand() stream
+on the host, gen_zipf's LUT search on the GPU). Per table kind one JSON line: device time of the probes (HIP events),
+probes per second, wall time including the host-bound generation, and the check totalMatches = |S|.
+
+    python tools/skew_config5.py [--log2r 28] [--slices 16] > profiles/rNN_skew_config5.jsonl"""
 import argparse
 import json
 import os
@@ -10,66 +12,49 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import htm_hashjoin_amd as hj
+import htm_hashjoin_amd as hj  # noqa: E402
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log2r", type=int, default=28)
-    ap.add_argument("--log2s", type=int, default=28)
-    ap.add_argument("--reps", type=int, default=16, help="the S sample is probed this many times")
+    ap.add_argument("--slices", type=int, default=16)
     ap.add_argument("--theta", type=float, default=0.9)
-    ap.add_argument("--rdist", default="local_shuffle")
-    ap.add_argument("--window", type=int, default=1024)
     a = ap.parse_args()
-    nr, ns = 1 << a.log2r, 1 << a.log2s
-    t0 = time.time()
-    import threading
-    stop = threading.Event()
-
-    def beat():                       # serial libc rand() streams take minutes at this size: show signs of life
-        while not stop.wait(60):
-            print(f"... generating, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
-    threading.Thread(target=beat, daemon=True).start()
-    R = hj.generate_data(a.rdist, nr, nr, a.window)
-    S = hj.generate_data("zipf", ns, nr, 16, zipf_theta=a.theta)
-    stop.set()
-    print(json.dumps({"datagen_s": round(time.time() - t0, 1), "rSize": nr, "sSize": ns, "theta": a.theta}), flush=True)
-    with hj.HashJoinContext(0) as ctx:
-        dR = ctx.dev_alloc(nr * 8); dS = ctx.dev_alloc(ns * 8)
-        ctx.copy_h2d(dR, R); ctx.copy_h2d(dS, S)
-        # open addressing: one build, `reps` probes of the sample
-        ctx.reserve("atomic", nr, ns)
-        best = None
-        for _ in range(2):
-            ctx.build(dR, nr)
-            probe_us = 0.0
-            for _ in range(a.reps):
-                ctx.probe(dS, ns)
-                r = ctx.fetch()
-                probe_us += r["probe_us"]
-            if best is None or r["build_us"] + probe_us < best[0]:
-                best = (r["build_us"] + probe_us, r, probe_us)
-        t, r, probe_us = best
-        probes = a.reps * ns
-        print(json.dumps({"algo": "atomic", "rSize": nr, "probes": probes, "conflicts": r["conflicts"],
-                          "totalMatches": r["totalMatches"], "all_probes_match": r["totalMatches"] == probes,
-                          "buildVariant": r["buildVariant"], "build_us": r["build_us"], "probe_us_total": probe_us,
-                          "mtuples_per_s": (nr + probes) / t,
-                          "probe_GBps_16B_per_tuple": 16.0 * probes / (probe_us * 1e-6) / 1e9}), flush=True)
-        # radix join: partitions R and the sample, joins; `reps` times for the same number of probes
-        with hj.HashJoinContext(0) as pctx:
-            pctx.reserve("prj", nr, ns)
-            tot_us, matches = 0.0, 0
-            for _ in range(a.reps):
-                pctx.prj_join(dR, nr, dS, ns)
-                r = pctx.fetch()
-                tot_us += r["total_us"]; matches += r["totalMatches"]
-            print(json.dumps({"algo": "prj", "rSize": nr, "probes": probes, "totalMatches": matches,
-                              "all_probes_match": matches == probes, "radixBits": r["radixBits"],
-                              "partition_us_last": r["partition_us"], "join_us_last": r["join_us"], "total_us": tot_us,
-                              "mtuples_per_s": a.reps * (nr + ns) / tot_us}), flush=True)
-        ctx.dev_free(dR); ctx.dev_free(dS)
+    n = per = 1 << a.log2r
+    R = hj.generate_data("local_shuffle", n, n, 1024)
+    for algo in ("atomic", "htm"):
+        with hj.HashJoinContext(0) as c:
+            dR = c.dev_alloc(n * 8); c.copy_h2d(dR, R)
+            dS = c.dev_alloc(per * 8)
+            c.reserve(algo, n, per)
+            c.build(dR, n)
+            built = c.fetch()
+            t0 = time.perf_counter()
+            c.zipf_open(n, a.theta, 0)
+            t_tables = time.perf_counter() - t0
+            probe_us, gen_s = 0.0, 0.0
+            t0 = time.perf_counter()
+            for _ in range(a.slices):
+                g0 = time.perf_counter()
+                c.zipf_next(per, dS)
+                gen_s += time.perf_counter() - g0
+                c.probe(dS, per)
+                probe_us += c.fetch()["probe_us"]
+            wall = time.perf_counter() - t0
+            c.zipf_close()
+            r = c.fetch()
+            total = a.slices * per
+            print(json.dumps({
+                "config": "skew stress (BASELINE configs[4])", "algo": algo, "rSize": n, "sSize": total, "distinct_draws": True,
+                "zipfTheta": a.theta, "slices": a.slices, "build_us": built["build_us"], "buildVariant": built["buildVariant"],
+                "probe_us_total": probe_us, "probes_per_s": total / (probe_us * 1e-6),
+                "probe_GBps_of_16B_per_probe": 16.0 * total / (probe_us * 1e-6) / 1e9,
+                "zipf_tables_s (alphabet permutation + LUT, host)": t_tables,
+                "wall_s_incl_host_rand_stream": wall, "host_rand_and_upload_s": gen_s,
+                "totalMatches": r["totalMatches"], "checks": {"every_probe_matches_once": r["totalMatches"] == total,
+                                                              "conflicts": r["conflicts"]}}), flush=True)
+            c.dev_free(dR); c.dev_free(dS)
 
 
 if __name__ == "__main__":

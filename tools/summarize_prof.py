@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Condenses rocprofv3 output directories into small CSV/JSON summaries for profiles/.
-usage: summarize_prof.py stats <dir> <out.csv> | pmc <dir> <out.json>"""
+usage: summarize_prof.py stats <dir> <out.csv> | pmc <dir> <out.json> | traffic <pmc_fetch.json> <pmc_write.json> <out.json>"""
 import collections
 import csv
 import glob
@@ -31,5 +31,24 @@ def pmc(d, out):
     json.dump(res, open(out, "w"), indent=1)
 
 
+def traffic(fetch_json, write_json, out):
+    """HBM bytes per launch and kernel = 2 * FETCH_SIZE + WRITE_SIZE (both counters are in KiB). FETCH_SIZE is doubled: on
+    gfx950 it reports half of the bytes of a wide coalesced streaming read (MI355X_MICROARCH.md, HBM; calibrated in round 1
+    on k_table_sums and on k_build_own, whose 512-byte-per-wave-instruction reads of R came out at exactly half of the
+    8.59 GB it reads once); WRITE_SIZE is exact for 16-byte-per-lane stores. bench.py reads this file for roofline.traffic."""
+    f, w = json.load(open(fetch_json)), json.load(open(write_json))
+    short = lambda k: k.replace("void ", "").replace("hj::", "").split("<")[0]          # noqa: E731
+    res = {}
+    for k in sorted(set(f) | set(w)):
+        fb = f.get(k, {}).get("FETCH_SIZE", {}).get("mean", 0.0) * 1024.0
+        wb = w.get(k, {}).get("WRITE_SIZE", {}).get("mean", 0.0) * 1024.0
+        res[short(k)] = res.get(short(k), 0.0) + 2.0 * fb + wb
+        res.setdefault("_raw", {})[k] = {"FETCH_SIZE_bytes_as_reported": fb, "WRITE_SIZE_bytes": wb}
+    res["_note"] = ("HBM bytes per launch, |R|=|S|=2^30 uniform, from separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of "
+                    "`python3 bench.py --steps 2 --warmup 1 --no-extra --no-cpu-baseline`; per kernel name 2 * FETCH_SIZE + WRITE_SIZE "
+                    "(template instances of one kernel summed per launch; see tools/summarize_prof.py: traffic)")
+    json.dump(res, open(out, "w"), indent=1)
+
+
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])
+    {"stats": stats, "pmc": pmc, "traffic": traffic}[sys.argv[1]](*sys.argv[2:])
