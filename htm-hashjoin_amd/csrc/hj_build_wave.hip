@@ -53,9 +53,6 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 #ifndef HJ_WV_PF
 #define HJ_WV_PF 1
 #endif
-#ifndef HJ_WV_ABL
-#define HJ_WV_ABL 0                                 // development only (tools/mk_variant.sh): timing ablations, results wrong
-#endif
 #ifndef HJ_WV_CARRY
 #define HJ_WV_CARRY 1                               // 1: leave < 64 retry entries queued across tiles
 #endif
@@ -153,34 +150,33 @@ k_wave_seams(const void* __restrict__ Rv, uint64_t n, uint32_t chunkLen, uint32_
 }
 
 // bounds[c] = max over chunks <= c of raw (chunks without a valid sample inherit), bounds[nChunks] = the table's
-// end. One wavefront: 64 chunks per step, prefix maximum by shuffles.
-__global__ void __launch_bounds__(64)
+// end. One workgroup: every thread takes a run of consecutive chunks, the runs' maxima are scanned through LDS.
+__global__ void __launch_bounds__(kBlock)
 k_wave_bounds_scan(const uint32_t* __restrict__ raw, uint32_t nChunks, uint32_t numGran, uint32_t* __restrict__ bounds, Gate gate)
 {
     if (gate_closed(gate)) return;
-    const uint32_t lane = threadIdx.x;
-    // the first valid sample opens the first range (nothing below it is owned)
-    uint32_t first = kNone;
-    for (uint32_t b = 0; b < nChunks && first == kNone; b += 64) {
-        const uint32_t v = b + lane < nChunks ? raw[b + lane] : kNone;
-        const unsigned long long m = __ballot(v != kNone);
-        if (m) first = (uint32_t)__shfl((int)v, __ffsll((long long)m) - 1, 64);
+    __shared__ uint32_t runMax[kBlock], sFirst;
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (nChunks + kBlock - 1) / kBlock, b = t * per, e = b + per < nChunks ? b + per : nChunks;
+    if (t == 0) sFirst = kNone;
+    __syncthreads();
+    // the first valid sample opens the first range (nothing below it is owned): lowest chunk index with a sample
+    uint32_t firstIdx = kNone, m = 0;
+    for (uint32_t c = b; c < e; ++c) {
+        const uint32_t v = raw[c];
+        if (v != kNone) { if (firstIdx == kNone) firstIdx = c; m = v > m ? v : m; }
     }
-    uint32_t run = first == kNone ? 0u : first;
-    for (uint32_t b = 0; b < nChunks; b += 64) {
-        uint32_t v = b + lane < nChunks ? raw[b + lane] : kNone;
-        v = v == kNone ? 0u : v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)v, off, 64);
-            if ((int)lane >= off) v = o > v ? o : v;
-        }
-        v = v > run ? v : run;
-        v = v < numGran ? v : numGran;
-        if (b + lane < nChunks) bounds[b + lane] = v;
-        run = (uint32_t)__shfl((int)v, 63, 64);
+    if (firstIdx != kNone) atomicMin(&sFirst, firstIdx);
+    runMax[t] = m;
+    __syncthreads();
+    uint32_t run = sFirst == kNone ? 0u : raw[sFirst];
+    for (uint32_t k = 0; k < t; ++k) run = runMax[k] > run ? runMax[k] : run;      // <= 255 LDS reads per thread
+    for (uint32_t c = b; c < e; ++c) {
+        const uint32_t v = raw[c];
+        if (v != kNone && v > run) run = v;
+        bounds[c] = run < numGran ? run : numGran;
     }
-    if (lane == 0) bounds[nChunks] = numGran;
+    if (t == 0) bounds[nChunks] = numGran;
 }
 
 // ---- the build ------------------------------------------------------------------------------------------------
@@ -238,7 +234,7 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
         while (winLoG < target) {
             ulonglong2* src = reinterpret_cast<ulonglong2*>(win + ((winLoG & (kWvGran - 1)) << kGranShift)) + lane;
             const ulonglong2 t = *src;
-            if (!(HJ_WV_ABL & 2)) reinterpret_cast<ulonglong2*>(table + ((uint64_t)winLoG << kGranShift))[lane] = t;
+            reinterpret_cast<ulonglong2*>(table + ((uint64_t)winLoG << kGranShift))[lane] = t;
             *src = make_ulonglong2(kEmpty, kEmpty);
             ++winLoG;
         }
@@ -408,7 +404,6 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
         // ---- the PER home-slot attempts of the tile, issued together (independent LDS round trips) ----
         unsigned long long oldv[kWvPer];
         uint32_t ownMask = 0;
-        if (HJ_WV_ABL & 1) continue;
 #pragma unroll
         for (int j = 0; j < kWvPer; ++j) {
             const bool own = ((liveMask >> j) & 1u) & in_ring(home[j]);
@@ -429,7 +424,7 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
             const bool disp = fail & (oldv[j] > mine);                 // ... by a later tuple: it moves on instead
             mlo = disp ? (uint32_t)oldv[j] : mlo; mhi = disp ? (uint32_t)(oldv[j] >> 32) : mhi;
             const uint32_t pos = fail ? ((home[j] + 1) & mask32) : home[j];
-            const bool again = (HJ_WV_ABL & 4) ? false : (fail | (lv & !own));   // outside ring or range: the retry round defers it
+            const bool again = fail | (lv & !own);                     // outside ring or range: the retry round defers it
             const unsigned long long am = __ballot(again);
             if (am) {
                 if (again) {
@@ -632,7 +627,7 @@ hipError_t launch_build_wave(const void* R, bool key32, uint64_t n, uint32_t hsh
     if (htm) hipLaunchKernelGGL((k_wave_seams<false, true>), gRaw, dim3(kBlock), 0, s, R, n, (uint32_t)chunkLen, nChunks, tableSize - 1, hshift, starts, raw, gate);
     else if (key32) hipLaunchKernelGGL((k_wave_seams<true, false>), gRaw, dim3(kBlock), 0, s, R, n, (uint32_t)chunkLen, nChunks, tableSize - 1, hshift, starts, raw, gate);
     else hipLaunchKernelGGL((k_wave_seams<false, false>), gRaw, dim3(kBlock), 0, s, R, n, (uint32_t)chunkLen, nChunks, tableSize - 1, hshift, starts, raw, gate);
-    hipLaunchKernelGGL(k_wave_bounds_scan, dim3(1), dim3(64), 0, s, raw, nChunks, numGran, bounds, gate);
+    hipLaunchKernelGGL(k_wave_bounds_scan, dim3(1), dim3(kBlock), 0, s, raw, nChunks, numGran, bounds, gate);
 #define HJ_WV_LAUNCH(K32, CHK, HTM)                                                                                  \
     hipLaunchKernelGGL((k_build_wave<K32, CHK, HTM>), gMain, dim3(kWvThreads), kWvLdsBytes, s, R, n, sliceLen,      \
                        nChunks, starts, bounds, table, tableSize - 1, hshift, probeLen, idxBase, sc,                         \
