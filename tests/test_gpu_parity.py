@@ -496,6 +496,32 @@ def test_maximum_relation_size():
     assert r["tableSumHalf"] == tri - n            # the nocc quirk: slots [0, rSize) miss key N, which sits in slot N
 
 
+def test_maximum_relation_size_on_the_wavefront_rings():
+    """The same size through build variant 3 (k_build_wave: slot numbers up to 2^32 - 1, 2^25 granules, 2^19-tuple chunks)
+    and the bucketised table (2^30 buckets = 2^32 slots): `sorted` R (the pre-round picks the rings), S = R."""
+    n = 1 << 31
+    R = hj.generate_data("sorted", n)
+    tri = n * (n + 1) // 2
+    with hj.HashJoinContext(0) as c:
+        dR = c.dev_alloc(n * 8); c.copy_h2d(dR, R)
+        del R
+        c.reserve("atomic", n, n)
+        c.build(dR, n); c.probe(dR, n)
+        c.checksums()
+        r = c.fetch()
+        assert (r["conflicts"], r["totalMatches"], r["inputSum"], r["tableSumFull"], r["buildVariant"], r["buildDeferred"]) == (
+            0, n, tri, tri, 3, 0)
+    with hj.HashJoinContext(0) as c:
+        c.reserve("htm", n, n)
+        c.build(dR, n); c.probe(dR, n)
+        c.checksums()
+        h = c.fetch()
+        assert (h["conflicts"], h["totalMatches"], h["inputSum"], h["outputSum"], h["htmBuckets"], h["buildVariant"]) == (
+            0, n, tri, tri, 1 << 30, 3)
+    with hj.HashJoinContext(0) as c:
+        c.dev_free(dR)
+
+
 # ---- radix-sharded path: every GPU kernel of htm_hashjoin_amd/sharded.py on one device ------------
 @pytest.mark.parametrize("G", [2, 8, 64])
 @pytest.mark.parametrize("dist,window", [("uniform", 16), ("local_shuffle", 1024), ("random", 16)])
