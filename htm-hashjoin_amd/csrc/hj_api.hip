@@ -457,21 +457,25 @@ static int build_htm(hj_ctx* c, const uint64_t* dR, uint64_t rSize, uint64_t idx
         HJ_HIP(c, launch_htm_build_global(dR, rSize, sl.sliceLen, sl.nChunks, c->table, slots, idxBase, c->htmConflicts,
                                           const_cast<uint32_t*>(sl.counts), c->dCtr, c->stream));
     }
-    // chains: count per bucket, reserve overflow buckets by one scan, fill them in index order, link
-    HJ_HIP(c, launch_htm_count(c->htmConflicts, sl.counts, sl.nChunks, sl.sliceLen, nb, c->htmOvfCount, c->htmOvfBase, c->stream));
-    HJ_HIP(c, launch_exclusive_scan_u32(c->htmOvfBase, nb, c->htmScan, c->stream));
+    // chains -- only if some bucket overflowed (one read-back of the conflict count): count per bucket, reserve overflow
+    // buckets by one scan, fill them in index order, link
     HJ_HIP(c, hipMemcpyAsync(c->hCtr, c->dCtr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
     HJ_HIP(c, hipStreamSynchronize(c->stream));
     const uint64_t conflicts = c->hCtr->conflicts;              // >= overflow buckets needed
-    if (conflicts + 1 > c->capHtmOverflow) {
-        if (c->htmOverflow) { HJ_HIP(c, hipFree(c->htmOverflow)); c->htmOverflow = nullptr; c->capHtmOverflow = 0; }
-        const uint64_t cap = conflicts + conflicts / 8 + 64;
-        HJ_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->htmOverflow), (cap + 1) * 4 * sizeof(uint64_t)));
-        c->capHtmOverflow = cap + 1;
-    }
     c->htmOverflowUsed = conflicts;
-    HJ_HIP(c, launch_htm_chains(c->htmConflicts, sl.counts, sl.nChunks, sl.sliceLen, c->table, nb, c->htmOvfCount, c->htmOvfBase,
-                                c->htmOverflow, conflicts, c->dCtr, c->stream));
+    if (conflicts) {
+        HJ_HIP(c, launch_htm_count(c->htmConflicts, sl.counts, sl.nChunks, sl.sliceLen, nb, c->htmOvfCount, c->htmOvfBase, c->stream));
+        HJ_HIP(c, launch_exclusive_scan_u32(c->htmOvfBase, nb, c->htmScan, c->stream));
+        if (conflicts + 1 > c->capHtmOverflow) {
+            HJ_HIP(c, hipStreamSynchronize(c->stream));
+            if (c->htmOverflow) { HJ_HIP(c, hipFree(c->htmOverflow)); c->htmOverflow = nullptr; c->capHtmOverflow = 0; }
+            const uint64_t cap = conflicts + conflicts / 8 + 64;
+            HJ_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->htmOverflow), (cap + 1) * 4 * sizeof(uint64_t)));
+            c->capHtmOverflow = cap + 1;
+        }
+        HJ_HIP(c, launch_htm_chains(c->htmConflicts, sl.counts, sl.nChunks, sl.sliceLen, c->table, nb, c->htmOvfCount, c->htmOvfBase,
+                                    c->htmOverflow, conflicts, c->dCtr, c->stream));
+    }
     if ((rc = record(c, EV_BUILD1))) return rc;
     c->built = true; c->htmBuilt = true;
     return HJ_OK;
@@ -688,22 +692,28 @@ int hj_export_buckets(hj_ctx* c, void* host_buckets, uint64_t numBuckets, void* 
     const uint64_t used = c->hCtr->htmOverflowBuckets;
     if (nOverflow) *nOverflow = used;
     if (used && (!host_overflows || overflowCap < used + 1)) return fail(c, HJ_ERR_INVALID, "hj_export_buckets: overflow buffer too small");
-    // device format (index << 32 | key, all ones = empty, slot 3 = next << 32 | count) -> struct Bucket {tuples[3], count, nextIndex}
-    auto convert = [](uint64_t* b, uint64_t n) {
+    // device format (index << 32 | key, all ones = empty; slot 3 = next << 32 | count, or all ones = "no chain") ->
+    // struct Bucket {tuples[3], count, nextIndex}; buckets [lo, hi) are the ones the build defined, the rest are empty
+    auto convert = [](uint64_t* b, uint64_t n, uint64_t lo, uint64_t hi) {
         for (uint64_t i = 0; i < n; ++i) {
             uint64_t* p = b + 4 * i;
-            const uint32_t count = (uint32_t)p[3], next = (uint32_t)(p[3] >> 32);
-            for (int j = 0; j < 3; ++j) p[j] = (p[j] == kEmpty) ? 0 : (uint32_t)p[j];
+            if (i < lo || i >= hi) { p[0] = p[1] = p[2] = p[3] = 0; continue; }
+            uint32_t count = 0;
+            for (int j = 0; j < 3; ++j) { count += p[j] != kEmpty; p[j] = (p[j] == kEmpty) ? 0 : (uint32_t)p[j]; }
+            const uint32_t next = p[3] == kEmpty ? 0u : (uint32_t)(p[3] >> 32);
             p[3] = (uint64_t)count | ((uint64_t)next << 32);     // little-endian {uint32 count; uint32 nextIndex}
         }
     };
+    const uint64_t defLo = c->hCtr->validLo >> 2;
+    uint64_t defHi = (c->hCtr->validHiEx + 512) >> 2;
+    defHi = defHi < numBuckets ? defHi : numBuckets;
     HJ_HIP(c, hipMemcpy(host_buckets, c->table, numBuckets * 32, hipMemcpyDeviceToHost));
-    convert(static_cast<uint64_t*>(host_buckets), numBuckets);
+    convert(static_cast<uint64_t*>(host_buckets), numBuckets, defLo, defHi);
     if (host_overflows) {
         memset(host_overflows, 0, 32);                           // index 0 is unused (as in the reference)
         if (used) {
             HJ_HIP(c, hipMemcpy(static_cast<char*>(host_overflows) + 32, c->htmOverflow + 4, used * 32, hipMemcpyDeviceToHost));
-            convert(static_cast<uint64_t*>(host_overflows) + 4, used);
+            convert(static_cast<uint64_t*>(host_overflows) + 4, used, 0, used);
         }
     }
     return HJ_OK;

@@ -7,8 +7,9 @@
 // (:291-305). TSX is replaced outright, not emulated:
 //
 //   layout   a bucket = 4 consecutive 8-byte slots = one 32-byte HBM sector: slots 0..2 hold (index << 32 | key),
-//            all-ones = empty; slot 3 = (next << 32 | count) once k_htm_link has run. Overflow buckets use the same
-//            format in a second array (index 0 unused, as in the reference).
+//            all-ones = empty; slot 3 = (next << 32 | count) for buckets with an overflow chain, all-ones otherwise
+//            (count = tuple slots in use, no chain). Overflow buckets use the same format in a second array (index 0
+//            unused, as in the reference). Buckets outside the slot range the build defined are never written.
 //   build    the three tuple slots are filled with the index-priority protocol of the open-addressing table
 //            (hj_kernels.hip) with a probe budget of 3 and home slot = the bucket's first slot (hj_device.h,
 //            home_slot_htm): whatever the scheduling, a bucket ends up with its three lowest-indexed tuples in
@@ -129,29 +130,20 @@ k_htm_fill_overflow(const uint64_t* __restrict__ conflicts, const uint32_t* __re
     }
 }
 
-// Counts and links: slot 3 of every primary bucket and of its overflow buckets. Primary buckets outside the slots the
-// build defined (Counters::validLo / validHiEx, hj_device.h) were never written: they become empty buckets here, so
-// the whole table is defined afterwards.
+// Links: slot 3 = (next << 32 | count) of every primary bucket THAT HAS CONFLICTS and of its overflow buckets. Every other
+// bucket keeps the all-ones word the build left there, which readers take as "no chain, count = tuple slots in use"
+// (htm_meta below) -- so a build without conflicts needs no pass over the table at all, and one with conflicts reads
+// 4 bytes per bucket here instead of rewriting 32.
 __global__ void __launch_bounds__(kBlock)
 k_htm_link(uint64_t* __restrict__ table, uint32_t numBuckets, const unsigned int* __restrict__ ovfCount,
            const uint32_t* __restrict__ ovfBase, uint64_t* __restrict__ overflow, Counters* __restrict__ ctr)
 {
-    const uint64_t defLo = ctr->validLo >> 2;
-    uint64_t defHi = (ctr->validHiEx + 512) >> 2;
-    defHi = defHi < numBuckets ? defHi : numBuckets;
     unsigned long long groupsSeen = 0;
     for (uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x; b < numBuckets; b += (uint64_t)gridDim.x * kBlock) {
-        ulonglong2* p = reinterpret_cast<ulonglong2*>(table + (b << 2));
-        if (b < defLo || b >= defHi) {
-            p[0] = make_ulonglong2(kEmpty, kEmpty);
-            p[1] = make_ulonglong2(kEmpty, 0ull);
-            continue;
-        }
-        const ulonglong2 a = p[0];
-        const uint64_t t2 = table[(b << 2) + 2];
-        const uint32_t count = (a.x != kEmpty) + (a.y != kEmpty) + (t2 != kEmpty);
-        const uint32_t oc = ovfCount[b], g = (oc + 2u) / 3u, first = ovfBase[b] + 1u;
-        table[(b << 2) + 3] = ((uint64_t)(g ? first + g - 1u : 0u) << 32) | count;          // head = the newest overflow bucket
+        const uint32_t oc = ovfCount[b];
+        if (oc == 0) continue;
+        const uint32_t g = (oc + 2u) / 3u, first = ovfBase[b] + 1u;
+        table[(b << 2) + 3] = ((uint64_t)(first + g - 1u) << 32) | 3u;                       // full bucket; head = the newest overflow bucket
         for (uint32_t j = 0; j < g; ++j)
             overflow[((uint64_t)(first + j) << 2) + 3] = ((uint64_t)(j ? first + j - 1u : 0u) << 32) | (j + 1 < g ? 3u : oc - 3u * (g - 1u));
         groupsSeen += g;
@@ -160,22 +152,29 @@ k_htm_link(uint64_t* __restrict__ table, uint32_t numBuckets, const unsigned int
     if ((threadIdx.x & 63) == 0 && groupsSeen) atomicAdd(&ctr->htmOverflowBuckets, groupsSeen);
 }
 
+// (count, next) of a bucket whose four words are a, b, c (tuple slots) and m (slot 3)
+__device__ __forceinline__ uint32_t htm_next(uint64_t m) { return m == kEmpty ? 0u : (uint32_t)(m >> 32); }
+
 // ---- probe: bucket, then its chain (HTMHashBuild.hpp:291-305) -----------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
 k_htm_probe(const uint64_t* __restrict__ S, uint64_t n, const uint64_t* __restrict__ table, uint32_t bucketMask,
             const uint64_t* __restrict__ overflow, Counters* __restrict__ ctr)
 {
     unsigned long long matches = 0;
+    // buckets outside the slots the build defined were never written and hold no tuple (hj_device.h, Counters)
+    const uint64_t defLo = ctr->validLo, defHi = ctr->validHiEx + 512;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
         const uint64_t s = S[i];
         if ((s >> 32) != 0 || s == 0) continue;                  // cannot equal any stored tuple
         const uint32_t key = (uint32_t)s;
-        const ulonglong2* p = reinterpret_cast<const ulonglong2*>(table + ((uint64_t)((key / 3u) & bucketMask) << 2));
+        const uint64_t slot = (uint64_t)((key / 3u) & bucketMask) << 2;
+        if (slot < defLo || slot + 3 >= defHi) continue;
+        const ulonglong2* p = reinterpret_cast<const ulonglong2*>(table + slot);
         for (;;) {
             const ulonglong2 a = p[0], c = p[1];
             matches += (a.x != kEmpty && (uint32_t)a.x == key) + (a.y != kEmpty && (uint32_t)a.y == key) +
                        (c.x != kEmpty && (uint32_t)c.x == key);
-            const uint32_t next = (uint32_t)(c.y >> 32);
+            const uint32_t next = htm_next(c.y);
             if (next == 0) break;
             p = reinterpret_cast<const ulonglong2*>(overflow + ((uint64_t)next << 2));
         }
@@ -189,13 +188,16 @@ __global__ void __launch_bounds__(kBlock)
 k_htm_sums(const uint64_t* __restrict__ table, uint32_t numBuckets, const uint64_t* __restrict__ overflow, Counters* __restrict__ ctr)
 {
     unsigned long long prim = 0, ovf = 0;
-    const uint64_t total = (uint64_t)numBuckets + ctr->htmOverflowBuckets;       // the overflow buckets k_htm_link linked
-    for (uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x; b < total; b += (uint64_t)gridDim.x * kBlock) {
-        const bool isOvf = b >= numBuckets;
-        const uint64_t* p = isOvf ? overflow + ((b - numBuckets + 1) << 2) : table + (b << 2);
-        const uint32_t count = (uint32_t)p[3];
+    const uint64_t defLo = ctr->validLo >> 2;
+    uint64_t defHi = (ctr->validHiEx + 512) >> 2;
+    defHi = defHi < numBuckets ? defHi : numBuckets;
+    const uint64_t nPrim = defHi > defLo ? defHi - defLo : 0;
+    const uint64_t total = nPrim + ctr->htmOverflowBuckets;                      // the overflow buckets k_htm_link linked
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (uint64_t)gridDim.x * kBlock) {
+        const bool isOvf = i >= nPrim;
+        const uint64_t* p = isOvf ? overflow + ((i - nPrim + 1) << 2) : table + ((defLo + i) << 2);
         unsigned long long sum = 0;
-        for (uint32_t j = 0; j < count && j < 3; ++j) sum += (uint32_t)p[j];
+        for (uint32_t j = 0; j < 3; ++j) sum += p[j] == kEmpty ? 0u : (uint32_t)p[j];
         if (isOvf) ovf += sum; else prim += sum;
     }
     prim = htm_wave_sum(prim); ovf = htm_wave_sum(ovf);
