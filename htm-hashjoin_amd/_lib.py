@@ -34,7 +34,8 @@ class hj_params(C.Structure):
         ("transactionSize", C.c_uint32),
         ("radixBits", C.c_uint32),
         ("buildVariant", C.c_uint32),
-        ("reserved", C.c_uint32 * 5),
+        ("prjMode", C.c_uint32),
+        ("reserved", C.c_uint32 * 4),
     ]
 
 
@@ -48,7 +49,7 @@ class hj_result(C.Structure):
         + [(n, C.c_double) for n in (
             "clear_us", "build_us", "probe_us", "partition_us", "join_us", "total_us", "h2d_us")]
         + [("buildDeferred", C.c_uint64), ("buildPhaseA_us", C.c_double), ("algoUsed", C.c_uint32),
-           ("reserved0", C.c_uint32), ("foreignTuples", C.c_uint64), ("prjScatterPass1R_us", C.c_double),
+           ("prjPath", C.c_uint32), ("foreignTuples", C.c_uint64), ("prjScatterPass1R_us", C.c_double),
            ("htmBuckets", C.c_uint64), ("htmOverflowBuckets", C.c_uint64), ("htmOverflowSum", C.c_uint64)]
     )
 

@@ -66,6 +66,7 @@ struct hj_ctx {
     uint32_t algoUsed = 0;
     size_t capWork = 0;
     bool prjRan = false;
+    bool prjOptimistic = false;   // the last radix join enqueued the histogram-free passes
     // staging for hj_run
     uint64_t *stageR = nullptr, *stageS = nullptr;
     uint64_t capStageR = 0, capStageS = 0;
@@ -266,7 +267,8 @@ int hj_reserve(hj_ctx* c, const hj_params* params, uint64_t rSize, uint64_t sSiz
             return fail(c, HJ_ERR_INVALID, "hj_reserve: PRJ sizes must be < 2^32 tuples per device");
         uint32_t bits = params->radixBits ? params->radixBits : auto_radix_bits(rSize);
         if (bits < 1 || bits > 16) return fail(c, HJ_ERR_INVALID, "hj_reserve: radixBits must be in [1,16]");
-        c->plan = prj_plan(rSize, sSize, bits);
+        if (params->prjMode > 2) return fail(c, HJ_ERR_INVALID, "hj_reserve: prjMode must be 0, 1 or 2");
+        c->plan = prj_plan(rSize, sSize, bits, params->prjMode);
         const uint64_t nmax = rSize > sSize ? rSize : sSize;
         int rc;
         // +2 tuples: the 16-byte sweeps may touch one tuple past an odd end
@@ -545,7 +547,7 @@ int hj_prj_join_dev(hj_ctx* c, const uint64_t* dR, uint64_t rSize, const uint64_
         return fail(c, HJ_ERR_STATE, "hj_prj_join_dev: hj_reserve() not called for these sizes");
     HJ_HIP(c, hipSetDevice(c->device));
     // the plan depends on the sizes (chunking); re-plan with the reserved bit count
-    const PrjPlan pl = prj_plan(rSize, dS ? sSize : 0, c->plan.radixBits);
+    const PrjPlan pl = prj_plan(rSize, dS ? sSize : 0, c->plan.radixBits, c->params.prjMode);
     if (pl.workspaceBytes > c->capWork) return fail(c, HJ_ERR_STATE, "hj_prj_join_dev: workspace too small");
     for (bool& b : c->evSet) b = false;
     c->built = false;
@@ -560,6 +562,7 @@ int hj_prj_join_dev(hj_ctx* c, const uint64_t* dR, uint64_t rSize, const uint64_
     if ((rc = record(c, EV_PRJ1))) return rc;
     HJ_HIP(c, hipGetLastError());
     c->prjRan = true;
+    c->prjOptimistic = pl.optimistic;
     c->algoUsed = HJ_ALGO_PRJ;
     return HJ_OK;
 }
@@ -634,6 +637,7 @@ int hj_fetch_result(hj_ctx* c, hj_result* out)
         out->join_us = elapsed_us(c, EV_PRJ_PART, EV_PRJ1);
         out->total_us = elapsed_us(c, EV_PRJ0, EV_PRJ1);
         out->prjScatterPass1R_us = elapsed_us(c, EV_PRJ_S0, EV_PRJ_S1);
+        out->prjPath = !c->prjOptimistic ? 0u : (k.prjFallback ? 2u : 1u);
     } else {
         out->conflicts = k.conflicts;
         out->conflictSum = k.conflictSum;

@@ -71,6 +71,9 @@ struct Counters {
     unsigned long long variant;
     // --algo htm (hj_htm.hip): overflow buckets linked, sum of the tuples they hold
     unsigned long long htmOverflowBuckets, htmOverflowSum;
+    // PRJ, histogram-free partitioning (hj_prj.hip): set to 1 by the scatter kernel that finds a fragment too small;
+    // the rest of that path then returns at once and the exact (histogram) path, gated on this word, runs instead
+    unsigned long long prjFallback;
 };
 
 // Device-side choice between the build variants (hj_build_dev must stay asynchronous: no host read-back). The host
@@ -173,9 +176,20 @@ size_t scan_workspace_words(uint64_t n);
 hipError_t launch_exclusive_scan_u32(uint32_t* data, uint64_t n, uint32_t* sums, hipStream_t s);
 
 // ---- PRJ (defined in hj_prj.hip) -------------------------------------------
+// Fragment geometry of the histogram-free partitioning of ONE relation (hj_prj.hip, "histogram-free partitioning"):
+// pass 1 cuts the relation into C1 chunks and writes bin b of chunk c to the fragment (b * C1 + c) of cap1 key slots;
+// pass 2 cuts every pass-1 partition (C1 fragments) into C2 chunks and writes to fragments of cap2 slots; a final
+// partition is C2 fragments. C = 0: the relation takes the exact path only.
+struct PrjFrag {
+    uint32_t C1, cap1, chunkLen1;
+    uint32_t C2, cap2, log2C2;
+};
 struct PrjPlan {
     uint32_t radixBits;   // total
     uint32_t bits1, bits2;
+    bool     optimistic;               // try the histogram-free path first (both relations qualify)
+    PrjFrag  fragR, fragS;
+    uint64_t cnt1Entries, cnt2EntriesR, cnt2EntriesS;   // fragment counters in the workspace
     uint64_t maxChunks1, maxChunks2;   // chunk descriptors per pass (upper bounds over both relations)
     uint64_t histEntries, scanBlocks;  // histogram / block-sum entries: the larger need of R's and S's layouts in
                                        // either pass (the chunk length, hence the chunk count, is NOT monotone in
@@ -184,7 +198,9 @@ struct PrjPlan {
 };
 // Sizes the workspace for (nR, nS): each relation is laid out with its own chunk length (run_pass), so every
 // region is the maximum over the two relations' layouts.
-PrjPlan prj_plan(uint64_t nR, uint64_t nS, uint32_t radixBits);
+// mode (hj_params.prjMode): 0 = histogram-free path for large relations, 1 = exact path only, 2 = histogram-free path
+// at any size it can be laid out for (tests)
+PrjPlan prj_plan(uint64_t nR, uint64_t nS, uint32_t radixBits, uint32_t mode = 0);
 // histogram entries the passes over ONE relation of n tuples write (what run_pass memsets and scans)
 uint64_t prj_hist_entries_needed(uint64_t n, uint32_t radixBits);
 struct PrjBuffers {

@@ -24,6 +24,7 @@
 
 #include "hj_device.h"
 
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 
@@ -35,6 +36,7 @@ constexpr uint32_t kJoinSlots = 32768;            // LDS table slots (uint32) = 
 constexpr uint32_t kJoinBlockTuples = 24576;      // R tuples per LDS build (load <= 0.75)
 constexpr int kJoinThreads = 1024;
 constexpr uint32_t kEmpty32 = 0xFFFFFFFFu;
+constexpr Gate kNoGate{nullptr, 0ull};
 
 struct PassParams {
     const uint32_t* segOff;     // [nSeg + 1] tuple offsets of the input segments
@@ -126,10 +128,11 @@ __device__ __forceinline__ uint64_t vec_tuple(const uint4& t)      // 8-byte for
 // ---------------------------------------------------------------------------
 template <bool IN32>
 __global__ void __launch_bounds__(kBlock)
-k_radix_hist(const void* __restrict__ in, PassParams p, uint32_t* __restrict__ hist)
+k_radix_hist(const void* __restrict__ in, PassParams p, uint32_t* __restrict__ hist, Gate gate)
 {
     constexpr uint32_t EPV = Fmt<IN32>::EPV;
     __shared__ unsigned int h[kMaxFan];
+    if (gate_closed(gate)) return;
     const uint32_t c = blockIdx.x;
     if (c >= p.chunkBase[p.nSeg]) return;
     const ChunkRange r = chunk_range(p, c);
@@ -225,9 +228,10 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
 }
 
 __global__ void __launch_bounds__(kBlock)
-k_scan_blocks(uint32_t* __restrict__ data, uint64_t n, uint32_t* __restrict__ blockSums)
+k_scan_blocks(uint32_t* __restrict__ data, uint64_t n, uint32_t* __restrict__ blockSums, Gate gate)
 {
     __shared__ uint32_t wsum[kBlock / 64];
+    if (gate_closed(gate)) return;
     const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanPerThread;
     uint32_t v[kScanPerThread], local = 0;
 #pragma unroll
@@ -246,9 +250,10 @@ k_scan_blocks(uint32_t* __restrict__ data, uint64_t n, uint32_t* __restrict__ bl
 }
 
 __global__ void __launch_bounds__(kBlock)
-k_scan_sums(uint32_t* __restrict__ sums, uint32_t m)
+k_scan_sums(uint32_t* __restrict__ sums, uint32_t m, Gate gate)
 {
     __shared__ uint32_t wsum[kBlock / 64];
+    if (gate_closed(gate)) return;
     uint32_t carry = 0;
     for (uint32_t base = 0; base < m; base += kBlock) {
         const uint32_t i = base + threadIdx.x;
@@ -261,8 +266,9 @@ k_scan_sums(uint32_t* __restrict__ sums, uint32_t m)
 }
 
 __global__ void __launch_bounds__(kBlock)
-k_scan_add(uint32_t* __restrict__ data, uint64_t n, const uint32_t* __restrict__ blockSums)
+k_scan_add(uint32_t* __restrict__ data, uint64_t n, const uint32_t* __restrict__ blockSums, Gate gate)
 {
+    if (gate_closed(gate)) return;
     const uint32_t add = blockSums[blockIdx.x];
     const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanPerThread;
 #pragma unroll
@@ -294,7 +300,7 @@ k_seg_offsets(PassParams p, const uint32_t* __restrict__ scanned, uint32_t nTota
 template <bool IN32, bool OUT32, int NT, int TV, bool PF = true, int WPE = 1>
 __global__ void __launch_bounds__(NT, WPE)
 k_radix_scatter(const void* __restrict__ in, void* __restrict__ outv, PassParams p,
-                const uint32_t* __restrict__ scanned)
+                const uint32_t* __restrict__ scanned, Gate gate)
 {
     static_assert(!(IN32 && !OUT32), "keys cannot become tuples again");
     constexpr uint32_t EPV = Fmt<IN32>::EPV;
@@ -317,6 +323,7 @@ k_radix_scatter(const void* __restrict__ in, void* __restrict__ outv, PassParams
     __shared__ unsigned int cursor[kMaxFan];
     __shared__ unsigned int sValid;
 
+    if (gate_closed(gate)) return;
     const uint32_t c = blockIdx.x;
     if (c >= p.chunkBase[p.nSeg]) return;
     const ChunkRange r = chunk_range(p, c);
@@ -444,6 +451,205 @@ k_radix_scatter(const void* __restrict__ in, void* __restrict__ outv, PassParams
 }
 
 // ---------------------------------------------------------------------------
+// histogram-free partitioning
+//   The exact passes above read everything twice: once to count, once to move (parallel_radix_partition :586-626 does
+//   the same). The counting exists only to make every partition one dense run. Here a pass does not count: chunk c of
+//   segment s owns, for every bin b, a private FRAGMENT of `outCap` key slots at ((s * fan + b) * C + c) * outCap and
+//   fills it from the front; what it wrote is recorded per fragment (outCnt). A partition is then C fragments with
+//   holes between them, which the next pass (reading positions, masking the holes by the counts) and the join (one
+//   fragment at a time) walk without ever compacting. outCap = mean + 7 sigma of a Poisson count (host: frag_cap), so
+//   DataGen-shaped inputs -- dense or uniformly drawn keys, whose low bits are uniform in every contiguous piece of
+//   the relation -- fit; a fragment that would overflow sets Counters::prjFallback, every kernel of this path
+//   returns at once when it sees the word set, and the exact passes, gated on the same word, redo the join.
+//   No atomics, no scan, no second read: 12 B (pass 1) and 8 B (pass 2) per tuple instead of 20 and 12.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kMaxInFrags = 1024;     // pass-1 fragments one pass-2 chunk may span (C1 <= 1024)
+
+struct FragPass {
+    uint32_t C;              // chunks per input segment = fragments per output partition
+    uint32_t shift, fan;
+    uint32_t outCap;         // key slots per output fragment (multiple of 32: whole 128-byte lines)
+    uint32_t* outCnt;        // [nSeg * fan * C] keys written per output fragment
+    // pass 1 (tuples in): one segment, the dense relation
+    uint32_t n, chunkLen;
+    // pass 2 (keys in): segment s = the inFrags * C fragments of pass-1 bin s, chunk c of it = fragments [c * inFrags, ..)
+    uint32_t inFrags, inCap;
+    const uint32_t* inCnt;
+};
+
+template <bool IN32, int NT>
+__global__ void __launch_bounds__(NT, 4)
+k_radix_scatter_frag(const void* __restrict__ in, uint32_t* __restrict__ out, FragPass p, Counters* __restrict__ ctr)
+{
+    constexpr int E = 16;                                     // elements per thread and tile
+    constexpr uint32_t TILE = (uint32_t)NT * E;
+    static_assert(TILE <= 65536, "rank is kept in 16 bits");
+    constexpr uint32_t kPadShift = 5;                         // see k_radix_scatter
+    constexpr uint32_t kDump = TILE + (TILE >> kPadShift);
+    __shared__ uint32_t stage[kDump + 1];
+    __shared__ unsigned int tileCnt[kMaxFan], tileOff[kMaxFan], delta[kMaxFan], cursor[kMaxFan];
+    __shared__ unsigned int sValid, sAbort;
+    __shared__ uint32_t prefix[IN32 ? kMaxInFrags + 1 : 1];   // pass 2: keys of this chunk before input fragment i
+    __shared__ uint32_t wsum[NT / 64];
+
+    if (*reinterpret_cast<volatile unsigned long long*>(&ctr->prjFallback)) return;
+    const uint32_t c = blockIdx.x;
+    const uint32_t seg = c / p.C, local = c - seg * p.C;
+    const uint32_t fmask = p.fan - 1;
+    // first slot of this chunk's fragment of bin b
+    auto frag_start = [&](uint32_t b) { return ((seg * p.fan + b) * p.C + local) * p.outCap; };
+
+    // ---- what this chunk reads: `total` elements, element d at ... ----
+    uint32_t total;                                            // elements of the chunk
+    uint32_t begin = 0;                                        // pass 1: first tuple
+    const uint32_t firstFrag = (seg * p.C + local) * p.inFrags;   // pass 2: first input fragment
+    if constexpr (!IN32) {
+        begin = local * p.chunkLen;
+        const uint32_t end = begin + p.chunkLen < p.n ? begin + p.chunkLen : p.n;   // host: n <= 2^31
+        total = begin < end ? end - begin : 0u;
+    } else {
+        // The holes between the input fragments are skipped, not masked: tiles are full (their runs whole 128-byte
+        // lines on dense keys), and nothing is read that is not a key. prefix[] = exclusive scan of the counts.
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < p.inFrags; base += NT) {
+            const uint32_t i = base + threadIdx.x;
+            const uint32_t v = i < p.inFrags ? p.inCnt[firstFrag + i] : 0u;
+            uint32_t sum;
+            const uint32_t ex = block_exclusive_scan<NT>(v, wsum, sum);
+            if (i < p.inFrags) prefix[i] = carry + ex;
+            carry += sum;
+        }
+        if (threadIdx.x == 0) prefix[p.inFrags] = carry;
+        total = carry;
+    }
+    if (total == 0) {                                           // the last chunks of a short relation
+        if (threadIdx.x < p.fan) p.outCnt[(seg * p.fan + threadIdx.x) * p.C + local] = 0;
+        return;
+    }
+    if (threadIdx.x < kMaxFan) {
+        tileCnt[threadIdx.x] = 0;
+        cursor[threadIdx.x] = threadIdx.x < p.fan ? frag_start(threadIdx.x) : 0;
+    }
+    if (threadIdx.x == 0) sAbort = 0;
+    __syncthreads();
+
+    const uint4* in4 = reinterpret_cast<const uint4*>(in);
+    const uint32_t* in1 = reinterpret_cast<const uint32_t*>(in);
+    const uint32_t lastVec = (begin + total - 1) / 2;          // pass 1: last 16-byte vector holding a tuple of the chunk
+    const uint32_t b0 = begin & ~1u;
+    uint32_t fA = 0;                                            // pass 2: input fragment the tile starts in
+    uint32_t tileNo = 0;
+    for (uint32_t T = 0; T < total + (IN32 ? 0u : begin - b0); T += TILE, ++tileNo) {
+        uint32_t tv[E], okMask = 0;
+        if constexpr (!IN32) {
+            // 8 vectors of two tuples per thread; the tile starts at the even tuple b0 + T
+            uint4 cur[E / 2];
+#pragma unroll
+            for (int k = 0; k < E / 2; ++k) {
+                const uint32_t v = (b0 + T) / 2 + (uint32_t)k * NT + threadIdx.x;
+                cur[k] = in4[v < lastVec ? v : lastVec];
+            }
+            const uint32_t rel0 = b0 + T - begin + 2 * threadIdx.x;   // wraps (= huge) before `begin`
+#pragma unroll
+            for (int k = 0; k < E / 2; ++k) {
+                const uint32_t rel = rel0 + 2u * (uint32_t)k * NT;
+                tv[2 * k] = cur[k].x; tv[2 * k + 1] = cur[k].z;
+                okMask |= (rel < total ? 1u : 0u) << (2 * k) | (rel + 1 < total ? 1u : 0u) << (2 * k + 1);
+            }
+        } else {
+            // element d of the chunk lives in input fragment f (prefix[f] <= d < prefix[f+1]) at slot d - prefix[f].
+            // A tile of 8192 elements meets few fragments: the first four are resolved by compares against
+            // wave-uniform bounds, anything beyond (tiny fragments) by a search.
+            while (fA + 1 < p.inFrags && prefix[fA + 1] <= T) ++fA;
+            uint32_t bound[4], start[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t f = fA + k < p.inFrags ? fA + k : p.inFrags - 1;
+                start[k] = (firstFrag + f) * p.inCap - prefix[f];
+                bound[k] = fA + k + 1 < p.inFrags ? prefix[fA + k + 1] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const uint32_t d = T + (uint32_t)j * NT + threadIdx.x;
+                const bool ok = d < total;
+                uint32_t at = d + (d >= bound[2] ? start[3] : d >= bound[1] ? start[2] : d >= bound[0] ? start[1] : start[0]);
+                if (ok && d >= bound[3]) {
+                    uint32_t f = fA + 4;
+                    while (f + 1 < p.inFrags && d >= prefix[f + 1]) ++f;
+                    at = (firstFrag + f) * p.inCap + d - prefix[f];
+                }
+                tv[j] = in1[ok ? at : firstFrag * p.inCap];
+                okMask |= (ok ? 1u : 0u) << j;
+            }
+        }
+        // ---- rank ----
+        uint32_t br[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const uint32_t bin = (tv[j] >> p.shift) & fmask;
+            br[j] = (bin << 16) | atomicAdd(&tileCnt[bin], (okMask >> j) & 1u);
+        }
+        __syncthreads();
+        // ---- one wavefront: scan of the counters, cursors, capacity check ----
+        if (threadIdx.x < 64) {
+            const uint32_t b4 = 4 * threadIdx.x;
+            uint32_t cnt[4], sum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { cnt[j] = tileCnt[b4 + j]; tileCnt[b4 + j] = 0; sum += cnt[j]; }
+            uint32_t inc = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t n = __shfl_up(inc, off, 64);
+                if ((int)threadIdx.x >= off) inc += n;
+            }
+            uint32_t ex = inc - sum;
+            bool over = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t cu = cursor[b4 + j];
+                tileOff[b4 + j] = ex;
+                delta[b4 + j] = cu - ex;
+                cursor[b4 + j] = cu + cnt[j];
+                over |= (b4 + j < p.fan) && (cu + cnt[j] - frag_start(b4 + j) > p.outCap);
+                ex += cnt[j];
+            }
+            // someone else's overflow: looked at every 16th tile (one wave-uniform load of a word nobody writes otherwise)
+            bool stop = __any(over);
+            if (!stop && (tileNo & 15u) == 15u) stop = *reinterpret_cast<volatile unsigned long long*>(&ctr->prjFallback) != 0;
+            if (threadIdx.x == 63) { sValid = inc; if (stop) sAbort = 1; }
+            if (threadIdx.x == 0 && __any(over)) atomicExch(&ctr->prjFallback, 1ull);
+        }
+        __syncthreads();
+        if (sAbort) return;                                     // nothing of this path is used any more
+        // ---- stage ----
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            const uint32_t at = tileOff[br[k] >> 16] + (br[k] & 0xFFFFu);
+            stage[((okMask >> k) & 1u) ? at + (at >> kPadShift) : kDump] = tv[k];
+        }
+        __syncthreads();
+        // ---- contiguous runs to HBM ----
+        const uint32_t valid = sValid;
+        auto emit = [&](uint32_t q) {
+            const uint32_t t = stage[q + (q >> kPadShift)];
+            out[delta[(t >> p.shift) & fmask] + q] = t;
+        };
+        if (valid == TILE) {
+#pragma unroll
+            for (int k = 0; k < E; ++k) emit((uint32_t)k * NT + threadIdx.x);
+        } else {
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                const uint32_t q = (uint32_t)k * NT + threadIdx.x;
+                if (q < valid) emit(q);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < p.fan) p.outCnt[(seg * p.fan + threadIdx.x) * p.C + local] = cursor[threadIdx.x] - frag_start(threadIdx.x);
+}
+
+// ---------------------------------------------------------------------------
 // per-partition join in LDS
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t next_pow2_u32(uint32_t v)
@@ -476,34 +682,93 @@ constexpr int kJoinPre = 16;   // tuples per thread and relation prefetched in r
 // most 16 bits, so the 128 KiB of LDS hold one 16-bit counter for EVERY possible k: build = one counter increment,
 // probe = one read, no hashing and no probe walks (the hash-table version spends 26 VALU instructions per tuple on
 // them, PMC). Counters cannot overflow while |R partition| <= 65535; larger ones take the hash-table path.
+// A relation's final partitions as the join sees them. Exact passes: partition pid = part[off[pid] .. off[pid+1]), one
+// dense run (cnt == nullptr, log2C = 0). Histogram-free passes: 2^log2C fragments of `cap` slots from pid << log2C,
+// fragment f holding cnt[(pid << log2C) + f] keys at its front.
+struct PartView {
+    const uint32_t* part;
+    const uint32_t* off;
+    const uint32_t* cnt;
+    uint32_t log2C, cap;
+    uint32_t total;          // slots of `part` that may be read (loads are clamped to total - 1)
+};
+struct PartGeom { uint32_t log2C, cap, total; };
+
+// The six arrays are separate __restrict__ parameters, not members of the views: only then does the compiler read the
+// offsets and counts (wave-uniform addresses) with scalar loads. As plain struct members they became vector loads
+// whose s_waitcnt vmcnt(0) also waited for the register prefetch of the next partition (join 1.6 -> 2.5 ms).
 template <bool DIRECT>
 __global__ void __launch_bounds__(kJoinThreads)
-k_prj_join(const uint32_t* __restrict__ partR, const uint32_t* __restrict__ offR,
-           const uint32_t* __restrict__ partS, const uint32_t* __restrict__ offS,
-           uint32_t radixBits, uint32_t nParts, uint32_t nRtotal, uint32_t nStotal, Counters* __restrict__ ctr)
+k_prj_join(const uint32_t* __restrict__ partR, const uint32_t* __restrict__ offR, const uint32_t* __restrict__ cntR, PartGeom gR,
+           const uint32_t* __restrict__ partS, const uint32_t* __restrict__ offS, const uint32_t* __restrict__ cntS, PartGeom gS,
+           uint32_t radixBits, uint32_t nParts, Counters* __restrict__ ctr, Gate gate)
 {
     extern __shared__ uint32_t tab[];  // kJoinSlots
+    if (gate_closed(gate)) return;
+    const PartView R{partR, offR, cntR, gR.log2C, gR.cap, gR.total}, S{partS, offS, cntS, gS.log2C, gS.cap, gS.total};
     unsigned long long matches = 0, checksum = 0;
     uint32_t overflowParts = 0;
-    const bool haveS = partS != nullptr;
+    const bool haveS = S.part != nullptr;
+
+    // slot j of the 16-deep register prefetch covers element ((j & (spf - 1)) * 1024 + thread) of fragment j >> spfShift
+    // (one dense run: 16 slots of the one fragment; 4 fragments: 4 slots each). A fragment longer than spf * 1024
+    // is finished by a loop over the rest.
+    const uint32_t spfShiftR = 4u - R.log2C, spfShiftS = 4u - S.log2C;
+    auto base_of = [](const PartView& v, uint32_t pid) { return v.cnt ? (pid << v.log2C) * v.cap : v.off[pid]; };
+    auto cnt_of = [](const PartView& v, uint32_t pid, uint32_t f) {
+        return v.cnt ? v.cnt[(pid << v.log2C) + f] : v.off[pid + 1] - v.off[pid];
+    };
+    auto slot_elem = [](uint32_t j, uint32_t spfShift) { return (j & ((1u << spfShift) - 1u)) * kJoinThreads + threadIdx.x; };
 
     // Register pipeline: S(p) is loaded while R(p) is built, R(p+1) while S(p) is probed; each buffer is
     // refilled only after its last use, so no copy of in-flight registers is ever needed.
     uint32_t bufR[kJoinPre], bufS[kJoinPre];   // partitions hold bare keys (see element formats above)
     auto load_R = [&](uint32_t pid) {   // clamped: every lane always loads a valid address; validity decided at use
-        const uint32_t rb0 = offR[pid < nParts ? pid : nParts - 1];
+        const uint32_t rb0 = base_of(R, pid < nParts ? pid : nParts - 1);
 #pragma unroll
         for (int j = 0; j < kJoinPre; ++j) {
-            const uint32_t o = rb0 + j * kJoinThreads + threadIdx.x;
-            bufR[j] = partR[o < nRtotal ? o : nRtotal - 1];
+            const uint32_t o = rb0 + ((uint32_t)j >> spfShiftR) * R.cap + slot_elem(j, spfShiftR);
+            bufR[j] = R.part[o < R.total ? o : R.total - 1];
         }
     };
     auto load_S = [&](uint32_t pid) {
-        const uint32_t sb0 = offS[pid];
+        const uint32_t sb0 = base_of(S, pid);
 #pragma unroll
         for (int j = 0; j < kJoinPre; ++j) {
-            const uint32_t o = sb0 + j * kJoinThreads + threadIdx.x;
-            bufS[j] = partS[o < nStotal ? o : nStotal - 1];
+            const uint32_t o = sb0 + ((uint32_t)j >> spfShiftS) * S.cap + slot_elem(j, spfShiftS);
+            bufS[j] = S.part[o < S.total ? o : S.total - 1];
+        }
+    };
+    // What a partition holds, read BEFORE any LDS work of the partition: the counts come through scalar loads, and
+    // waiting for one (lgkmcnt) also waits for every LDS atomic in flight -- a count looked up between two atomics
+    // serialises them (measured: join 1.6 -> 2.5 ms). mask bit j = prefetch slot j holds a key; tail = some fragment
+    // is longer than the prefetch covers.
+    struct Shape { uint32_t n, mask; bool tail; };
+    auto shape_of = [&](const PartView& v, uint32_t pid, uint32_t spfShift) {
+        Shape sh{0u, 0u, false};
+        const uint32_t spf = 1u << spfShift;                       // prefetch slots per fragment
+        for (uint32_t fr = 0; fr < (1u << v.log2C); ++fr) {        // one scalar load per fragment
+            const uint32_t n = cnt_of(v, pid, fr);
+            sh.n += n;
+            sh.tail |= n > (kJoinThreads << spfShift);
+            // this thread's slots of the fragment hold elements thread, thread + 1024, ...: the first `mine` are keys
+            uint32_t mine = n > threadIdx.x ? (n - threadIdx.x + kJoinThreads - 1) / kJoinThreads : 0u;
+            mine = mine < spf ? mine : spf;
+            sh.mask |= ((1u << mine) - 1u) << (fr << spfShift);
+        }
+        return sh;
+    };
+    // f(key) for every key of partition pid: the prefetched slots out of `buf`, the rest of long fragments from memory
+    auto for_each = [&](const PartView& v, uint32_t pid, uint32_t spfShift, const Shape& sh, const uint32_t (&buf)[kJoinPre], auto&& f) {
+#pragma unroll
+        for (int j = 0; j < kJoinPre; ++j)
+            if ((sh.mask >> j) & 1u) f(buf[j]);
+        if (sh.tail) {
+            const uint32_t b = base_of(v, pid);
+            for (uint32_t fr = 0; fr < (1u << v.log2C); ++fr) {
+                const uint32_t n = cnt_of(v, pid, fr);
+                for (uint32_t i = (kJoinThreads << spfShift) + threadIdx.x; i < n; i += kJoinThreads) f(v.part[b + fr * v.cap + i]);
+            }
         }
     };
     load_R(blockIdx.x);
@@ -514,81 +779,69 @@ k_prj_join(const uint32_t* __restrict__ partR, const uint32_t* __restrict__ offR
         if (haveS) load_S(pid);                                // in flight while R is built
         __builtin_amdgcn_sched_barrier(0);
 
-        const uint32_t rb = offR[pid], re = offR[pid + 1];
-        const uint32_t nR = re - rb;
+        const Shape shR = shape_of(R, pid, spfShiftR);
+        const Shape shS = haveS ? shape_of(S, pid, spfShiftS) : Shape{0u, 0u, false};
+        const uint32_t nR = shR.n;
         if (nR == 0) {          // serial_radix_partition :531 queues only non-empty R parts (wave-uniform)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             load_R(pid + gridDim.x);
             continue;
         }
-        const uint32_t sb = haveS ? offS[pid] : 0, se = haveS ? offS[pid + 1] : 0;
-        const uint32_t nS = se - sb;
         const uint32_t idxMask = next_pow2_u32(nR) - 1;  // bucket idx mask, :242-245
 
         if (DIRECT && nR <= 65535u) {
             // ---- direct-addressed counters: tab[k >> 1] holds the counts of k = 2i (low half) and 2i + 1 (high half) ----
             for (uint32_t i = threadIdx.x; i < kJoinSlots; i += kJoinThreads) tab[i] = 0u;
             __syncthreads();
-#pragma unroll
-            for (int j = 0; j < kJoinPre; ++j) {
-                if (j * kJoinThreads + threadIdx.x < nR) {
-                    const uint32_t k = bufR[j] >> radixBits;
-                    checksum += k & idxMask;                          // :249,256
-                    atomicAdd(&tab[k >> 1], 1u << (16u * (k & 1u)));
-                }
-            }
-            for (uint32_t i = rb + kJoinPre * kJoinThreads + threadIdx.x; i < re; i += kJoinThreads) {
-                const uint32_t k = partR[i] >> radixBits;
-                checksum += k & idxMask;
+            for_each(R, pid, spfShiftR, shR, bufR, [&](uint32_t key) {
+                const uint32_t k = key >> radixBits;
+                checksum += k & idxMask;                          // :249,256
                 atomicAdd(&tab[k >> 1], 1u << (16u * (k & 1u)));
-            }
+            });
             __syncthreads();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // S(pid) has landed; bufR is free
             __builtin_amdgcn_sched_barrier(0);
             load_R(pid + gridDim.x);                           // in flight while S is probed
             __builtin_amdgcn_sched_barrier(0);
-            uint32_t m32 = 0;                                  // <= 65535 per probe, a few dozen probes per thread
+            if (haveS) {
+                uint32_t m32 = 0;                              // <= 65535 per probe, a few dozen probes per thread
 #pragma unroll
-            for (int j = 0; j < kJoinPre; ++j) {
-                if (j * kJoinThreads + threadIdx.x < nS) {
-                    const uint32_t k = bufS[j] >> radixBits;
-                    m32 += (tab[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;      // :268-271, all equal keys at once
+                for (int j = 0; j < kJoinPre; ++j)
+                    if ((shS.mask >> j) & 1u) {
+                        const uint32_t k = bufS[j] >> radixBits;
+                        m32 += (tab[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;      // :268-271, all equal keys at once
+                    }
+                matches += m32;
+                if (shS.tail) {
+                    const uint32_t sb = base_of(S, pid);
+                    for (uint32_t fr = 0; fr < (1u << S.log2C); ++fr) {
+                        const uint32_t n = cnt_of(S, pid, fr);
+                        for (uint32_t i = (kJoinThreads << spfShiftS) + threadIdx.x; i < n; i += kJoinThreads) {
+                            const uint32_t k = S.part[sb + fr * S.cap + i] >> radixBits;
+                            matches += (tab[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;
+                        }
+                    }
                 }
-            }
-            matches += m32;
-            for (uint32_t i = sb + kJoinPre * kJoinThreads + threadIdx.x; i < se; i += kJoinThreads) {
-                const uint32_t k = partS[i] >> radixBits;
-                matches += (tab[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;
             }
             __syncthreads();
         } else if (nR <= kJoinBlockTuples) {
             // ---- the common case: the whole R partition fits one LDS table ----
             for (uint32_t i = threadIdx.x; i < kJoinSlots; i += kJoinThreads) tab[i] = kEmpty32;
             __syncthreads();
-#pragma unroll
-            for (int j = 0; j < kJoinPre; ++j) {
-                if (j * kJoinThreads + threadIdx.x < nR) {
-                    const uint32_t k = bufR[j] >> radixBits;   // distinguishes keys inside a partition
-                    checksum += k & idxMask;                          // :249,256
-                    uint32_t h = join_hash(k);
-                    while (atomicCAS(&tab[h], kEmpty32, k) != kEmpty32) h = (h + 1) & (kJoinSlots - 1);
-                }
-            }
-            for (uint32_t i = rb + kJoinPre * kJoinThreads + threadIdx.x; i < re; i += kJoinThreads) {   // tuples 16384..
-                const uint32_t k = partR[i] >> radixBits;
-                checksum += k & idxMask;
+            for_each(R, pid, spfShiftR, shR, bufR, [&](uint32_t key) {
+                const uint32_t k = key >> radixBits;           // distinguishes keys inside a partition
+                checksum += k & idxMask;                          // :249,256
                 uint32_t h = join_hash(k);
                 while (atomicCAS(&tab[h], kEmpty32, k) != kEmpty32) h = (h + 1) & (kJoinSlots - 1);
-            }
+            });
             __syncthreads();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // S(pid) has landed; bufR is free
             __builtin_amdgcn_sched_barrier(0);
             load_R(pid + gridDim.x);                           // in flight while S is probed
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < kJoinPre; ++j) {
-                if (j * kJoinThreads + threadIdx.x < nS) {
-                    const uint32_t k = bufS[j] >> radixBits;
+            if (haveS)
+                for_each(S, pid, spfShiftS, shS, bufS, [&](uint32_t key) {
+                    const uint32_t k = key >> radixBits;
                     uint32_t h = join_hash(k);
                     for (;;) {
                         const uint32_t v = tab[h];
@@ -596,37 +849,29 @@ k_prj_join(const uint32_t* __restrict__ partR, const uint32_t* __restrict__ offR
                         matches += (v == k);                          // :268-271
                         h = (h + 1) & (kJoinSlots - 1);
                     }
-                }
-            }
-            for (uint32_t i = sb + kJoinPre * kJoinThreads + threadIdx.x; i < se; i += kJoinThreads) {
-                const uint32_t k = partS[i] >> radixBits;
-                uint32_t h = join_hash(k);
-                for (;;) {
-                    const uint32_t v = tab[h];
-                    if (v == kEmpty32) break;
-                    matches += (v == k);
-                    h = (h + 1) & (kJoinSlots - 1);
-                }
-            }
+                });
             __syncthreads();
         } else {
-            // ---- oversized R partition (skew): several LDS builds, S probed against each ----
+            // ---- oversized R partition (skew): several LDS builds, S probed against each. Exact layout only: the
+            // histogram-free passes are not planned for partitions that could outgrow one table (prj_plan)
             overflowParts += 1;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             load_R(pid + gridDim.x);
+            const uint32_t rb = R.off[pid], re = R.off[pid + 1];
+            const uint32_t sb = haveS ? S.off[pid] : 0, se = haveS ? S.off[pid + 1] : 0;
             for (uint32_t blk = rb; blk < re; blk += kJoinBlockTuples) {
                 const uint32_t bend = (re - blk > kJoinBlockTuples) ? blk + kJoinBlockTuples : re;
                 for (uint32_t i = threadIdx.x; i < kJoinSlots; i += kJoinThreads) tab[i] = kEmpty32;
                 __syncthreads();
                 for (uint32_t i = blk + threadIdx.x; i < bend; i += kJoinThreads) {
-                    const uint32_t k = partR[i] >> radixBits;
+                    const uint32_t k = R.part[i] >> radixBits;
                     checksum += k & idxMask;
                     uint32_t h = join_hash(k);
                     while (atomicCAS(&tab[h], kEmpty32, k) != kEmpty32) h = (h + 1) & (kJoinSlots - 1);
                 }
                 __syncthreads();
                 for (uint32_t i = sb + threadIdx.x; i < se; i += kJoinThreads) {
-                    const uint32_t k = partS[i] >> radixBits;
+                    const uint32_t k = S.part[i] >> radixBits;
                     uint32_t h = join_hash(k);
                     for (;;) {
                         const uint32_t v = tab[h];
@@ -678,13 +923,68 @@ static PassLayout pass_layout(uint64_t n, uint32_t nSeg, uint32_t fan)
     return l;
 }
 
-PrjPlan prj_plan(uint64_t nR, uint64_t nS, uint32_t radixBits)
+// Slots of a fragment that is to hold a Poisson-distributed number of keys of the given mean: mean + 7 sigma (one
+// fragment in 10^12 is larger; a run has ~10^6 of them) + a little for tiny means, in whole 16-byte vectors.
+static uint32_t frag_cap(double mean)
+{
+    // whole 128-byte lines: a tile leaves runs of 128 bytes per bin, and with fragments that start inside a line every one
+    // of them straddles two (measured at 2^30: 14.8 ms of partitioning with 4580-slot fragments, 12.5 ms with 4576)
+    const double c = mean + 7.0 * std::sqrt(mean) + 32.0;
+    return ((uint32_t)c + 31u) & ~31u;
+}
+
+constexpr uint64_t kFragMinTuples = 1ull << 25;      // below this the exact passes take well under a millisecond
+constexpr double kFragMinMean = 256.0;               // smaller fragments are mostly slack
+
+// Fragment geometry of one relation, or C1 = 0 when it has to take the exact passes.
+static PrjFrag frag_geometry(uint64_t n, uint32_t radixBits, uint32_t bits1, uint32_t bits2, uint32_t mode)
+{
+    PrjFrag g{};
+    if (n == 0 || bits2 == 0 || mode == 1 || n > (1ull << 31)) return g;
+    if (mode == 0 && n < kFragMinTuples) return g;
+    const uint32_t F1 = 1u << bits1, F2 = 1u << bits2;
+    // pass 1: as many chunks as two rounds of workgroups (2 per CU), fewer while the fragments would get short
+    uint32_t C1 = kMaxInFrags;
+    while (C1 > 256 && (double)n / C1 / F1 < 2048.0) C1 >>= 1;
+    while (C1 > 1 && (double)n / C1 / F1 < kFragMinMean) C1 >>= 1;
+    const uint64_t chunkLen1 = ((n + C1 - 1) / C1 + kTile - 1) / kTile * kTile;
+    const double mean1 = (double)chunkLen1 / F1;
+    if (mean1 < kFragMinMean) return g;
+    const uint32_t cap1 = frag_cap(mean1);
+    // pass 2: ~1024 chunks in all, each a whole number of pass-1 fragments; the join wants <= 16 fragments per partition
+    uint32_t C2 = 1024 / F1 ? 1024 / F1 : 1;
+    if (C2 > 16) C2 = 16;
+    if (C2 > C1) C2 = C1;
+    auto mean2_of = [&](uint32_t c2) { return (double)(C1 / c2) * mean1 / F2; };
+    while (C2 > 1 && mean2_of(C2) < kFragMinMean) C2 >>= 1;
+    const double mean2 = mean2_of(C2);
+    if (mean2 < kFragMinMean) return g;
+    const uint32_t cap2 = frag_cap(mean2);
+    // the buffers hold 8 bytes per tuple (hj_reserve), the positions are 32-bit, and a partition must fit one LDS table
+    const uint64_t slots1 = (uint64_t)F1 * C1 * cap1, slots2 = (uint64_t)F1 * F2 * C2 * cap2;
+    if (slots1 > 2 * n || slots2 > 2 * n || slots1 >= (1ull << 32) || slots2 >= (1ull << 32)) return g;
+    if ((uint64_t)C2 * cap2 > (radixBits >= 16 ? 65535u : kJoinBlockTuples)) return g;
+    g.C1 = C1; g.cap1 = cap1; g.chunkLen1 = (uint32_t)chunkLen1;
+    g.C2 = C2; g.cap2 = cap2;
+    while ((1u << g.log2C2) < C2) ++g.log2C2;
+    return g;
+}
+
+PrjPlan prj_plan(uint64_t nR, uint64_t nS, uint32_t radixBits, uint32_t mode)
 {
     PrjPlan pl{};
     pl.radixBits = radixBits;
     if (radixBits <= 8) { pl.bits1 = radixBits; pl.bits2 = 0; }
     else { pl.bits1 = radixBits / 2; pl.bits2 = radixBits - pl.bits1; }  // prj_thread :814-816
     const uint32_t F1 = 1u << pl.bits1, F2 = 1u << pl.bits2;
+    pl.fragR = frag_geometry(nR, radixBits, pl.bits1, pl.bits2, mode);
+    pl.fragS = frag_geometry(nS, radixBits, pl.bits1, pl.bits2, mode);
+    pl.optimistic = pl.fragR.C1 != 0 && (nS == 0 || pl.fragS.C1 != 0);
+    if (pl.optimistic) {
+        pl.cnt1Entries = (uint64_t)F1 * (pl.fragR.C1 > pl.fragS.C1 ? pl.fragR.C1 : pl.fragS.C1);
+        pl.cnt2EntriesR = (uint64_t)F1 * F2 * pl.fragR.C2;
+        pl.cnt2EntriesS = (uint64_t)F1 * F2 * pl.fragS.C2;
+    }
     // run_pass lays every relation out with pick_chunk_len of ITS size, and the chunk count is not monotone in
     // the size (chunkLen doubles at the 8192 -> 16384 step: |R| = 40e6 has fewer chunks than |S| = 2^25), so
     // each region takes the larger of the two relations' needs, pass by pass
@@ -707,6 +1007,8 @@ PrjPlan prj_plan(uint64_t nR, uint64_t nS, uint32_t radixBits)
     bytes += align_up(sizeof(uint32_t) * pl.histEntries, 256);  // hist / scanned
     bytes += align_up(sizeof(uint32_t) * (pl.scanBlocks + 1), 256);   // block sums
     bytes += 2 * align_up(sizeof(uint32_t) * (P + 1), 256);     // final offsets R, S
+    bytes += align_up(sizeof(uint32_t) * pl.cnt1Entries, 256);  // fragment counters: pass 1 (R, then S), pass 2 of R, of S
+    bytes += align_up(sizeof(uint32_t) * pl.cnt2EntriesR, 256) + align_up(sizeof(uint32_t) * pl.cnt2EntriesS, 256);
     pl.workspaceBytes = bytes;
     return pl;
 }
@@ -722,7 +1024,7 @@ uint64_t prj_hist_entries_needed(uint64_t n, uint32_t radixBits)
 
 namespace {
 struct Work {
-    uint32_t *seg0, *seg1, *chunkBase, *hist, *sums, *offR, *offS;
+    uint32_t *seg0, *seg1, *chunkBase, *hist, *sums, *offR, *offS, *cnt1, *cnt2R, *cnt2S;
 };
 Work carve(const PrjPlan& pl, void* base)
 {
@@ -736,14 +1038,17 @@ Work carve(const PrjPlan& pl, void* base)
     w.hist = reinterpret_cast<uint32_t*>(p); p += align_up(sizeof(uint32_t) * pl.histEntries, 256);
     w.sums = reinterpret_cast<uint32_t*>(p); p += align_up(sizeof(uint32_t) * (pl.scanBlocks + 1), 256);
     w.offR = reinterpret_cast<uint32_t*>(p); p += align_up(sizeof(uint32_t) * (P + 1), 256);
-    w.offS = reinterpret_cast<uint32_t*>(p);
+    w.offS = reinterpret_cast<uint32_t*>(p); p += align_up(sizeof(uint32_t) * (P + 1), 256);
+    w.cnt1 = reinterpret_cast<uint32_t*>(p); p += align_up(sizeof(uint32_t) * pl.cnt1Entries, 256);
+    w.cnt2R = reinterpret_cast<uint32_t*>(p); p += align_up(sizeof(uint32_t) * pl.cnt2EntriesR, 256);
+    w.cnt2S = reinterpret_cast<uint32_t*>(p);
     return w;
 }
 
 // One radix pass: in -> out, segments segIn[nSeg+1] -> segOut[nSeg*fan+1].
 // in32: the input already holds bare keys (pass 2); the output always does.
 hipError_t run_pass(const void* in, bool in32, uint32_t* out, uint64_t n, const uint32_t* segIn, uint32_t nSeg,
-                    uint32_t shift, uint32_t bits, uint32_t* segOut, const Work& w, hipStream_t s,
+                    uint32_t shift, uint32_t bits, uint32_t* segOut, const Work& w, Gate gate, hipStream_t s,
                     hipEvent_t evScatter0 = nullptr, hipEvent_t evScatter1 = nullptr)
 {
     const uint32_t fan = 1u << bits;
@@ -753,11 +1058,11 @@ hipError_t run_pass(const void* in, bool in32, uint32_t* out, uint64_t n, const 
     // entries past the live chunks must be zero for the scan to be a prefix of live data only
     const hipError_t e = hipMemsetAsync(w.hist, 0, sizeof(uint32_t) * l.histEntries, s);
     if (e != hipSuccess) return e;
-    if (in32) hipLaunchKernelGGL(k_radix_hist<true>, dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s, in, p, w.hist);
-    else hipLaunchKernelGGL(k_radix_hist<false>, dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s, in, p, w.hist);
-    hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)l.scanBlocks), dim3(kBlock), 0, s, w.hist, l.histEntries, w.sums);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, s, w.sums, (uint32_t)l.scanBlocks);
-    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)l.scanBlocks), dim3(kBlock), 0, s, w.hist, l.histEntries, w.sums);
+    if (in32) hipLaunchKernelGGL(k_radix_hist<true>, dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s, in, p, w.hist, gate);
+    else hipLaunchKernelGGL(k_radix_hist<false>, dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s, in, p, w.hist, gate);
+    hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)l.scanBlocks), dim3(kBlock), 0, s, w.hist, l.histEntries, w.sums, gate);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, s, w.sums, (uint32_t)l.scanBlocks, gate);
+    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)l.scanBlocks), dim3(kBlock), 0, s, w.hist, l.histEntries, w.sums, gate);
     const uint32_t nOut = nSeg * fan + 1;
     hipLaunchKernelGGL(k_seg_offsets, dim3((nOut + kBlock - 1) / kBlock), dim3(kBlock), 0, s, p, w.hist, (uint32_t)n, segOut);
     // instance choice measured at 2^30 (tools/prj_variants.sh, profiles/r01_prj_variants.txt): 512 threads x 16
@@ -765,22 +1070,37 @@ hipError_t run_pass(const void* in, bool in32, uint32_t* out, uint64_t n, const 
     // prefetching instance were slower or equal
     if (evScatter0) (void)hipEventRecord(evScatter0, s);
     if (in32) hipLaunchKernelGGL((k_radix_scatter<true, true, 512, 4, false, 4>), dim3((unsigned)l.maxChunks), dim3(512), 0, s,
-                                 in, static_cast<void*>(out), p, w.hist);
+                                 in, static_cast<void*>(out), p, w.hist, gate);
     else hipLaunchKernelGGL((k_radix_scatter<false, true, 512, 8, false, 4>), dim3((unsigned)l.maxChunks), dim3(512), 0, s,
-                            in, static_cast<void*>(out), p, w.hist);
+                            in, static_cast<void*>(out), p, w.hist, gate);
     if (evScatter1) (void)hipEventRecord(evScatter1, s);
     return hipGetLastError();
 }
 
 hipError_t partition_relation(const PrjPlan& pl, const Work& w, const uint64_t* in, uint64_t n,
-                              uint32_t* tmp, uint32_t* out, uint32_t* finalOff, hipStream_t s,
+                              uint32_t* tmp, uint32_t* out, uint32_t* finalOff, Gate gate, hipStream_t s,
                               hipEvent_t evS0 = nullptr, hipEvent_t evS1 = nullptr)
 {
     hipLaunchKernelGGL(k_init_seg, dim3(1), dim3(64), 0, s, w.seg0, (uint32_t)n);
-    if (pl.bits2 == 0) return run_pass(in, false, out, n, w.seg0, 1, 0, pl.bits1, finalOff, w, s, evS0, evS1);
-    const hipError_t e = run_pass(in, false, tmp, n, w.seg0, 1, 0, pl.bits1, w.seg1, w, s, evS0, evS1);   // pass 1, R = 0: tuples -> keys
+    if (pl.bits2 == 0) return run_pass(in, false, out, n, w.seg0, 1, 0, pl.bits1, finalOff, w, gate, s, evS0, evS1);
+    const hipError_t e = run_pass(in, false, tmp, n, w.seg0, 1, 0, pl.bits1, w.seg1, w, gate, s, evS0, evS1);   // pass 1, R = 0: tuples -> keys
     if (e != hipSuccess) return e;
-    return run_pass(tmp, true, out, n, w.seg1, 1u << pl.bits1, pl.bits1, pl.bits2, finalOff, w, s);    // pass 2, R = bits1
+    return run_pass(tmp, true, out, n, w.seg1, 1u << pl.bits1, pl.bits1, pl.bits2, finalOff, w, gate, s);    // pass 2, R = bits1
+}
+
+// The two histogram-free passes over one relation: tuples -> fragments of tmp -> fragments of out, counts in cnt2.
+hipError_t partition_relation_frag(const PrjPlan& pl, const PrjFrag& g, const Work& w, const uint64_t* in, uint64_t n,
+                                   uint32_t* tmp, uint32_t* out, uint32_t* cnt2, Counters* ctr, hipStream_t s,
+                                   hipEvent_t evS0 = nullptr, hipEvent_t evS1 = nullptr)
+{
+    const uint32_t F1 = 1u << pl.bits1, F2 = 1u << pl.bits2;
+    const FragPass p1{g.C1, 0u, F1, g.cap1, w.cnt1, (uint32_t)n, g.chunkLen1, 0u, 0u, nullptr};
+    if (evS0) (void)hipEventRecord(evS0, s);
+    hipLaunchKernelGGL((k_radix_scatter_frag<false, 512>), dim3(g.C1), dim3(512), 0, s, static_cast<const void*>(in), tmp, p1, ctr);
+    if (evS1) (void)hipEventRecord(evS1, s);
+    const FragPass p2{g.C2, pl.bits1, F2, g.cap2, cnt2, 0u, 0u, g.C1 / g.C2, g.cap1, w.cnt1};
+    hipLaunchKernelGGL((k_radix_scatter_frag<true, 512>), dim3(F1 * g.C2), dim3(512), 0, s, static_cast<const void*>(tmp), out, p2, ctr);
+    return hipGetLastError();
 }
 }  // namespace
 
@@ -792,21 +1112,41 @@ hipError_t launch_prj(const PrjPlan& pl, const PrjBuffers& buf, const uint64_t* 
     uint32_t* const tmp = reinterpret_cast<uint32_t*>(buf.tmpA);
     uint32_t* const partR = reinterpret_cast<uint32_t*>(buf.partR);
     uint32_t* const partS = reinterpret_cast<uint32_t*>(buf.partS);
-    hipError_t e = partition_relation(pl, w, R, nR, tmp, partR, w.offR, s, evScatter0, evScatter1);
-    if (e != hipSuccess) return e;
-    if (S && (e = partition_relation(pl, w, S, nS, tmp, partS, w.offS, s)) != hipSuccess) return e;
+    hipError_t e;
+    // Histogram-free passes first (Counters::prjFallback is 0: the caller zeroed the counters); the exact passes are
+    // enqueued behind them and return at once unless a fragment overflowed.
+    Gate exact = kNoGate;
+    if (pl.optimistic) {
+        if ((e = partition_relation_frag(pl, pl.fragR, w, R, nR, tmp, partR, w.cnt2R, ctr, s, evScatter0, evScatter1)) != hipSuccess) return e;
+        if (S && (e = partition_relation_frag(pl, pl.fragS, w, S, nS, tmp, partS, w.cnt2S, ctr, s)) != hipSuccess) return e;
+        exact = Gate{&ctr->prjFallback, 1ull};
+        evScatter0 = evScatter1 = nullptr;
+    }
+    if ((e = partition_relation(pl, w, R, nR, tmp, partR, w.offR, exact, s, evScatter0, evScatter1)) != hipSuccess) return e;
+    if (S && (e = partition_relation(pl, w, S, nS, tmp, partS, w.offS, exact, s)) != hipSuccess) return e;
     if (evPartDone && (e = hipEventRecord(evPartDone, s)) != hipSuccess) return e;
     const uint32_t P = 1u << pl.radixBits;
     const unsigned grid = P < (uint32_t)nCU ? P : (unsigned)nCU;   // one persistent workgroup per CU
     static_assert(kJoinSlots * 2 == 65536, "two 16-bit counters per LDS word cover every 16-bit key remainder");
-    if (pl.radixBits >= 16)
-        hipLaunchKernelGGL(k_prj_join<true>, dim3(grid), dim3(kJoinThreads), kJoinSlots * sizeof(uint32_t), s,
-                       (const uint32_t*)partR, w.offR, S ? (const uint32_t*)partS : nullptr, w.offS, pl.radixBits, P, (uint32_t)nR,
-                       (uint32_t)(S ? nS : 1), ctr);
-    else
-        hipLaunchKernelGGL(k_prj_join<false>, dim3(grid), dim3(kJoinThreads), kJoinSlots * sizeof(uint32_t), s,
-                       (const uint32_t*)partR, w.offR, S ? (const uint32_t*)partS : nullptr, w.offS, pl.radixBits, P, (uint32_t)nR,
-                       (uint32_t)(S ? nS : 1), ctr);
+    const PartView none{nullptr, nullptr, nullptr, 0u, 0u, 1u};
+    auto join = [&](const PartView& vr, const PartView& vs, Gate gate) {
+        if (pl.radixBits >= 16)
+            hipLaunchKernelGGL(k_prj_join<true>, dim3(grid), dim3(kJoinThreads), kJoinSlots * sizeof(uint32_t), s,
+                               vr.part, vr.off, vr.cnt, PartGeom{vr.log2C, vr.cap, vr.total},
+                               vs.part, vs.off, vs.cnt, PartGeom{vs.log2C, vs.cap, vs.total}, pl.radixBits, P, ctr, gate);
+        else
+            hipLaunchKernelGGL(k_prj_join<false>, dim3(grid), dim3(kJoinThreads), kJoinSlots * sizeof(uint32_t), s,
+                               vr.part, vr.off, vr.cnt, PartGeom{vr.log2C, vr.cap, vr.total},
+                               vs.part, vs.off, vs.cnt, PartGeom{vs.log2C, vs.cap, vs.total}, pl.radixBits, P, ctr, gate);
+    };
+    if (pl.optimistic) {
+        const PartView vr{partR, nullptr, w.cnt2R, pl.fragR.log2C2, pl.fragR.cap2, P * pl.fragR.C2 * pl.fragR.cap2};
+        const PartView vs{partS, nullptr, w.cnt2S, pl.fragS.log2C2, pl.fragS.cap2, P * pl.fragS.C2 * pl.fragS.cap2};
+        join(vr, S ? vs : none, Gate{&ctr->prjFallback, 0ull});
+    }
+    const PartView er{partR, w.offR, nullptr, 0u, 0u, (uint32_t)nR};
+    const PartView es{partS, w.offS, nullptr, 0u, 0u, (uint32_t)nS};
+    join(er, S ? es : none, exact);
     return hipGetLastError();
 }
 
@@ -1041,10 +1381,10 @@ hipError_t launch_shard_hist(const uint64_t* in, uint64_t n, uint32_t nShards, u
     PassParams p{w.seg0, 1u, l.chunkLen, w.chunkBase, digitShift & 0xFFu, nShards, (digitShift >> 8) & 1u, 1u};
     const hipError_t e = hipMemsetAsync(w.hist, 0, sizeof(uint32_t) * l.histEntries, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_radix_hist<false>, dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s, static_cast<const void*>(in), p, w.hist);
-    hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)l.scanBlocks), dim3(kBlock), 0, s, w.hist, l.histEntries, w.sums);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, s, w.sums, (uint32_t)l.scanBlocks);
-    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)l.scanBlocks), dim3(kBlock), 0, s, w.hist, l.histEntries, w.sums);
+    hipLaunchKernelGGL(k_radix_hist<false>, dim3((unsigned)l.maxChunks), dim3(kBlock), 0, s, static_cast<const void*>(in), p, w.hist, kNoGate);
+    hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)l.scanBlocks), dim3(kBlock), 0, s, w.hist, l.histEntries, w.sums, kNoGate);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, s, w.sums, (uint32_t)l.scanBlocks, kNoGate);
+    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)l.scanBlocks), dim3(kBlock), 0, s, w.hist, l.histEntries, w.sums, kNoGate);
     hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(kBlock), 0, s, p, w.hist, (uint32_t)n, w.segOut);
     hipLaunchKernelGGL(k_shard_counts, dim3(1), dim3(64), 0, s, w.segOut, nShards, counts);
     return hipGetLastError();
@@ -1073,9 +1413,9 @@ hipError_t launch_exclusive_scan_u32(uint32_t* data, uint64_t n, uint32_t* sums,
 {
     const uint64_t blocks = (n + kScanTile - 1) / kScanTile;
     if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)blocks), dim3(kBlock), 0, s, data, n, sums);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, s, sums, (uint32_t)blocks);
-    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)blocks), dim3(kBlock), 0, s, data, n, sums);
+    hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)blocks), dim3(kBlock), 0, s, data, n, sums, kNoGate);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, s, sums, (uint32_t)blocks, kNoGate);
+    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)blocks), dim3(kBlock), 0, s, data, n, sums, kNoGate);
     return hipGetLastError();
 }
 

@@ -61,11 +61,12 @@ def generate_relation(kind, num_tuples, maxid=None, local_shuffle_range=0, zipf_
 
 
 def _params(algo, scaleOutput=2, numPartitions=64, probeLength=4, transactionSize=16, radixBits=0,
-            buildVariant=0):
+            buildVariant=0, prjMode=0):
     p = hj_params()
     p.algo = _lib.ALGO_IDS[algo]
     p.scaleOutput, p.numPartitions, p.probeLength = scaleOutput, numPartitions, probeLength
     p.transactionSize, p.radixBits, p.buildVariant = transactionSize, radixBits, buildVariant
+    p.prjMode = prjMode
     return p
 
 

@@ -85,7 +85,11 @@ typedef struct {
                                  3 = wavefront-private LDS rings over statically owned slot
                                  ranges (tight locality, the reference's default
                                  --shuffleRange 16); all give the same table            */
-    uint32_t reserved[5];
+    uint32_t prjMode;         /* PRJ: 0 = partition large relations without histograms (fragments
+                                 sized for uniform low key bits, checked; the exact passes of
+                                 parallel_radix_join.c:586-626 run instead when one overflows);
+                                 1 = exact passes only; 2 = as 0 at any size that can be laid out   */
+    uint32_t reserved[4];
 } hj_params;
 
 /* Everything the reference prints in its JSON line (NoCCHashBuild.hpp:127-146,
@@ -118,7 +122,8 @@ typedef struct {
                                  k_build_deferred)                                   */
     uint32_t algoUsed;        /* hj_algo that produced this result (differs from
                                  hj_params.algo only for HJ_ALGO_AUTO)               */
-    uint32_t reserved0;
+    uint32_t prjPath;         /* PRJ: 0 = exact (histogram) passes; 1 = histogram-free passes;
+                                 2 = histogram-free passes overflowed, exact passes redid the join */
     uint64_t foreignTuples;   /* hj_set_shard_check: build + probe tuples whose
                                  destination is another shard (0 when the check is off) */
     double   prjScatterPass1R_us; /* PRJ: device time of the pass-1 scatter of R alone (the

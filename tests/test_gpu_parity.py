@@ -392,6 +392,53 @@ def test_prj_ragged_skewed_and_r_only(ctx):
     assert got["totalMatches"] == 0 and got["prjChecksum"] == oracle.prj_join(R, None, 14)["checksum"]
 
 
+@pytest.mark.parametrize("dist,window,nS", [("uniform", 16, None), ("shuffle", 16, 20_000_003), ("local_shuffle", 1024, None),
+                                            ("sorted", 16, (1 << 24) + 4099)])
+@pytest.mark.parametrize("n,bits", [(1 << 24, 14), (1 << 24, 16), (19_999_999, 15)])
+def test_prj_histogram_free_passes_match_oracle(ctx, dist, window, nS, n, bits):
+    """prjMode 2: the histogram-free passes (fragments + counts instead of dense partitions) at sizes the oracle joins in
+    seconds; same matches and the same PRO checksum as the exact passes, and the path really was the one taken."""
+    R = oracle.generate_data(dist, n, n, window)
+    S = oracle.relS_for(dist, R) if nS is None else hj.generate_data("uniform", nS, n, 16)
+    want = oracle.prj_join(R, S, bits)
+    got = ctx.run("prj", R, S, radixBits=bits, prjMode=2)
+    # DataGen's `uniform` is (rand() & (distinct - 1)) + 1 (DataGen.hpp:41): with a `distinct` that is no power of two the
+    # mask has holes, whole residue classes of the low bits never occur, and the fragments of the others overflow
+    masked = (n & (n - 1)) != 0 and (dist == "uniform" or nS is not None)
+    assert got["prjPath"] == (2 if masked else 1), got
+    assert (got["totalMatches"], got["prjChecksum"]) == (want["matches"], want["checksum"])
+    exact = ctx.run("prj", R, S, radixBits=bits, prjMode=1)
+    assert exact["prjPath"] == 0
+    assert (exact["totalMatches"], exact["prjChecksum"]) == (want["matches"], want["checksum"])
+
+
+@pytest.mark.parametrize("skewed", ["R", "S", "S-pass2"])
+def test_prj_histogram_free_passes_fall_back_on_skew(ctx, skewed):
+    """A fragment that would overflow (low key bits far from uniform) sets the fallback word on the device; the exact
+    passes enqueued behind redo the join. Skew in R's pass 1, in S's pass 1 (after R went through), in a pass 2."""
+    n, bits = 1 << 24, 14
+    rng = np.random.default_rng(5)
+    R = oracle.generate_data("shuffle", n)
+    S = hj.generate_data("uniform", n, n, 16)
+    if skewed == "R":
+        R = (rng.integers(1, 1 << 17, size=n, dtype=np.uint64) << np.uint64(7)) | np.uint64(3)       # one pass-1 bin
+    elif skewed == "S":
+        S = (rng.integers(1, 1 << 17, size=n, dtype=np.uint64) << np.uint64(7)) | np.uint64(3)
+    else:
+        S = (rng.integers(1, 1 << 10, size=n, dtype=np.uint64) << np.uint64(14)) | rng.integers(0, 128, size=n, dtype=np.uint64)
+        S[S == 0] = 1                                                                               # pass-2 bin 0 only
+    want = oracle.prj_join(R, S, bits)
+    got = ctx.run("prj", R, S, radixBits=bits, prjMode=2)
+    assert got["prjPath"] == 2, got
+    assert (got["totalMatches"], got["prjChecksum"]) == (want["matches"], want["checksum"])
+    # the same context afterwards, on well-behaved input: the word is reset with the counters
+    R2 = oracle.generate_data("shuffle", n)
+    want = oracle.prj_join(R2, S, bits)
+    got = ctx.run("prj", R2, S, radixBits=bits, prjMode=2)
+    assert got["prjPath"] == (1 if skewed == "R" else 2)
+    assert (got["totalMatches"], got["prjChecksum"]) == (want["matches"], want["checksum"])
+
+
 @pytest.mark.parametrize("nR,nS", [(40_000_000, 1 << 25), (1 << 25, 40_000_000)])
 def test_prj_unequal_sizes_across_the_chunk_length_step(nR, nS):
     """|R| and |S| on opposite sides of the size where the partitioning chunk length doubles: the smaller relation
@@ -405,7 +452,7 @@ def test_prj_unequal_sizes_across_the_chunk_length_step(nR, nS):
         # AUTO with a non-power-of-two |R| is the radix join too
         for algo in ("prj", "auto") if nR & (nR - 1) else ("prj",):
             got = c.run(algo, R, S, radixBits=14)
-            assert got["algoUsed"] == "prj"
+            assert got["algoUsed"] == "prj" and got["prjPath"] == 1     # both >= 2^25: the histogram-free passes
             assert (got["totalMatches"], got["prjChecksum"]) == (want["matches"], want["checksum"]), algo
 
 
