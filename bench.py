@@ -144,10 +144,14 @@ def prj_leg(torch, hj, ctx, n, dist, window, steps, warmup, S_dev):
         "mtuples_per_s": 2 * n / (dt / steps) / 1e6,
         "partition_us": res["partition_us"], "join_us": res["join_us"],
         "totalMatches": res["totalMatches"],
+        # 1 = the histogram-free passes held (12 + 8 + 4 = 24 B per tuple), 2 = they overflowed and the exact passes
+        # (32 B per tuple: every pass reads its input twice) redid the join, 0 = exact passes only
+        "prjPath": res["prjPath"],
         "hbm_frac_of_32B_per_tuple": 32.0 * 2 * n / (dt / steps) / 1e9 / HBM_PEAK_GBPS,
+        "hbm_frac_of_24B_per_tuple": 24.0 * 2 * n / (dt / steps) / 1e9 / HBM_PEAK_GBPS,
         # dominant kernel of the radix join: the pass-1 scatter (tuples in, keys out: 8 B read + 4 B written per tuple),
         # HIP-event timed on the launch stream for R's launch (hj_result.prjScatterPass1R_us)
-        "roofline": {"bound": "hbm", "kernel": "k_radix_scatter (pass 1, R)", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+        "roofline": {"bound": "hbm", "kernel": ("k_radix_scatter_frag<false>" if res["prjPath"] == 1 else "k_radix_scatter") + " (pass 1, R)", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
                      "algorithmic_bytes_per_launch": 12.0 * n, "launch_us": res["prjScatterPass1R_us"],
                      "achieved": 12.0 * n / (res["prjScatterPass1R_us"] * 1e-6) / 1e9 if res["prjScatterPass1R_us"] else None,
                      "frac": 12.0 * n / (res["prjScatterPass1R_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS if res["prjScatterPass1R_us"] else None,

@@ -944,7 +944,7 @@ static PrjFrag frag_geometry(uint64_t n, uint32_t radixBits, uint32_t bits1, uin
     if (mode == 0 && n < kFragMinTuples) return g;
     const uint32_t F1 = 1u << bits1, F2 = 1u << bits2;
     // pass 1: as many chunks as two rounds of workgroups (2 per CU), fewer while the fragments would get short
-    uint32_t C1 = kMaxInFrags;
+    uint32_t C1 = kMaxInFrags;      // 512 .. 4096 measured at 2^30: 11.8 - 11.9 ms throughout
     while (C1 > 256 && (double)n / C1 / F1 < 2048.0) C1 >>= 1;
     while (C1 > 1 && (double)n / C1 / F1 < kFragMinMean) C1 >>= 1;
     const uint64_t chunkLen1 = ((n + C1 - 1) / C1 + kTile - 1) / kTile * kTile;
