@@ -72,12 +72,14 @@ def test_config3_prj_local_shuffle_1024_closed_forms():
         dR = c.dev_alloc(N * 8); c.copy_h2d(dR, R)
         del R
         dS = c.dev_alloc(N * 8); c.copy_h2d(dS, np.arange(1, N + 1, dtype=np.uint64))
-        c.reserve("prj", N, N)
-        c.prj_join(dR, N, dS, N)
-        p = c.fetch()
-        assert p["radixBits"] == 16 and p["prjPartitions"] == 1 << 16
-        assert p["totalMatches"] == N
-        assert p["prjChecksum"] == pro_closed_form(N, 16)
+        for mode, path in ((0, 1), (1, 0)):         # the histogram-free passes (what the bench times), then the exact ones
+            c.reserve("prj", N, N, prjMode=mode)
+            c.prj_join(dR, N, dS, N)
+            p = c.fetch()
+            assert p["prjPath"] == path
+            assert p["radixBits"] == 16 and p["prjPartitions"] == 1 << 16
+            assert p["totalMatches"] == N
+            assert p["prjChecksum"] == pro_closed_form(N, 16)
         with hj.HashJoinContext(0) as c2:          # the same relation through the table join: inputSum and the unique-key sums
             c2.reserve("atomic", N, N)
             c2.build(dR, N); c2.probe(dS, N); c2.checksums()
