@@ -8,6 +8,9 @@
 //                    every partition's tuples leave the CU as contiguous runs
 //   k_prj_join       bucket_chaining_join (:231-283) with the probe loop the fork
 //                    commented out (:259-276) restored; the table lives in LDS
+//   k_radix_scatter_frag  the same two passes WITHOUT the histogram loops (the default for large
+//                    relations): private fragments per chunk and bin, capacity checked, the exact
+//                    kernels above enqueued behind as a gated fallback (see "histogram-free partitioning")
 // Orchestration (prj_thread :808-1122: 6 pthread barriers, 2 task queues) becomes
 // stream order between kernels.
 //
