@@ -589,7 +589,11 @@ int hj_join_dev(hj_ctx* c, const uint64_t* dR, uint64_t rSize, const uint64_t* d
         uint32_t v = 1;
         if ((canOwn || canWave) && c->params.buildVariant != 1 &&
             (rc = sample_variant(c, dR, false, rSize, 2 * rSize, 0, canOwn, canWave, &v))) return rc;
-        prj = v == 1;                 // no locality: both table phases would be random HBM accesses
+        // no locality: both table phases would be random HBM accesses. Loose locality (variant 2) pays for every tuple
+        // that leaves its window with global atomics: at 2^27, local_shuffle W=2^11 (3.8 % deferred) the table join
+        // takes 2.06 ms against the radix join's 1.89 ms, at W=2^10 0.99 against 1.88 (profiles/r02_sweep.jsonl): the
+        // radix join from 1/64 of the sample outside the window.
+        prj = v == 1 || (v == 2 && (uint64_t)c->hFit[0] * 64u > c->hFit[1]);
         force = v;
     }
     if (prj) return hj_prj_join_dev(c, dR, rSize, dS, sSize);
