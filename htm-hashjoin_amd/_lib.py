@@ -91,6 +91,7 @@ def _declare(lib):
         "hj_copy_h2d": ([vp, vp, vp, u64], i32),
         "hj_copy_d2h": ([vp, vp, vp, u64], i32),
         "hj_prj_workspace_info": ([u64, u64, u32, P(u64)], i32),
+        "hj_prj_fragment_info": ([u64, u64, u32, u32, P(u64)], i32),
         "hj_zipf_open": ([vp, u64, C.c_double, C.c_uint], i32),
         "hj_zipf_next_dev": ([vp, u64, vp], i32),
         "hj_zipf_close": ([vp], i32),

@@ -746,6 +746,21 @@ int hj_run(hj_ctx* c, const hj_params* params, const uint64_t* relR, uint64_t rS
     return hj_fetch_result(c, out);
 }
 
+int hj_prj_fragment_info(uint64_t rSize, uint64_t sSize, uint32_t radixBits, uint32_t prjMode, uint64_t out[13])
+{
+    if (!out || radixBits > 16 || prjMode > 2) return HJ_ERR_INVALID;
+    const uint32_t bits = radixBits ? radixBits : auto_radix_bits(rSize);
+    const PrjPlan pl = prj_plan(rSize, sSize, bits, prjMode);
+    out[0] = pl.optimistic ? 1 : 0;
+    const PrjFrag* g[2] = {&pl.fragR, &pl.fragS};
+    for (int k = 0; k < 2; ++k) {
+        uint64_t* o = out + 1 + 5 * k;
+        o[0] = g[k]->C1; o[1] = g[k]->cap1; o[2] = g[k]->chunkLen1; o[3] = g[k]->C2; o[4] = g[k]->cap2;
+    }
+    out[11] = pl.bits1; out[12] = pl.bits2;
+    return HJ_OK;
+}
+
 int hj_prj_workspace_info(uint64_t rSize, uint64_t sSize, uint32_t radixBits, uint64_t out[4])
 {
     if (!out || radixBits > 16) return HJ_ERR_INVALID;

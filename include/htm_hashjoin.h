@@ -252,6 +252,12 @@ int hj_set_shard_check(hj_ctx *ctx, uint32_t nShards, uint32_t mode, uint32_t sh
  * passes over R / over S write. Each relation is chunked by its own size (mc's per-thread slices,
  * parallel_radix_join.c:586-617, become per-chunk histograms), so out[1] >= max(out[2], out[3]) must hold. */
 int hj_prj_workspace_info(uint64_t rSize, uint64_t sSize, uint32_t radixBits, uint64_t out[4]);
+/* Host-only arithmetic: the fragment geometry of the histogram-free passes for (rSize, sSize, radixBits, prjMode).
+ * out[0] = 1 when those passes would be enqueued (both relations qualify), else 0 (exact passes only);
+ * out[1..5] = R's chunks of pass 1, slots per pass-1 fragment, tuples per pass-1 chunk, chunks of pass 2 per pass-1
+ * partition (= fragments per final partition), slots per pass-2 fragment; out[6..10] = the same for S; out[11], out[12] =
+ * radix bits of pass 1 and pass 2. A relation with out[1] (out[6]) == 0 does not qualify. */
+int hj_prj_fragment_info(uint64_t rSize, uint64_t sSize, uint32_t radixBits, uint32_t prjMode, uint64_t out[13]);
 
 /* ---- device memory for hosts without a HIP runtime of their own ----------- */
 int hj_dev_alloc(hj_ctx *ctx, uint64_t bytes, void **dptr);
