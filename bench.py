@@ -126,6 +126,15 @@ def oa_leg(torch, hj, ctx, n, dist, window, steps, warmup, S_dev=None, variant=0
     return out, S_dev
 
 
+def prj_traffic(n, dist, window, path):
+    """HBM bytes of the pass-1 scatter of R from the committed PMC passes (profiles/pmc_traffic.json), for the one workload
+    they were taken on; None otherwise."""
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not (os.path.exists(pmc) and n == 1 << 30 and dist == "local_shuffle" and window == 1024 and path == 1):
+        return None
+    return json.load(open(pmc)).get("k_radix_scatter_frag_pass1_R_local_shuffle_1024")
+
+
 def prj_leg(torch, hj, ctx, n, dist, window, steps, warmup, S_dev):
     R = hj.generate_data(dist, n, n, window)
     R_dev = to_device(R, torch, "cuda")
@@ -155,7 +164,7 @@ def prj_leg(torch, hj, ctx, n, dist, window, steps, warmup, S_dev):
                      "algorithmic_bytes_per_launch": 12.0 * n, "launch_us": res["prjScatterPass1R_us"],
                      "achieved": 12.0 * n / (res["prjScatterPass1R_us"] * 1e-6) / 1e9 if res["prjScatterPass1R_us"] else None,
                      "frac": 12.0 * n / (res["prjScatterPass1R_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS if res["prjScatterPass1R_us"] else None,
-                     "traffic": None},
+                     "traffic": prj_traffic(n, dist, window, res["prjPath"])},
         "checks": {"matches_eq_n": res["totalMatches"] == n},
     }
 
