@@ -439,6 +439,26 @@ def test_prj_histogram_free_passes_fall_back_on_skew(ctx, skewed):
     assert (got["totalMatches"], got["prjChecksum"]) == (want["matches"], want["checksum"])
 
 
+def test_prj_histogram_free_passes_r_only_small_s_and_auto(ctx):
+    """Who takes the histogram-free passes: R alone (the fork's PRO: no probe) does; a large R with a small S does not
+    (both relations must qualify, else everything goes through the exact passes); AUTO's radix join does."""
+    n = 1 << 25
+    R = oracle.generate_data("shuffle", n)
+    got = ctx.run("prj", R, None, radixBits=14)
+    assert got["prjPath"] == 1 and got["totalMatches"] == 0
+    assert got["prjChecksum"] == oracle.prj_join(R, None, 14)["checksum"]
+    S = oracle.generate_data("shuffle", 100_000)
+    want = oracle.prj_join(R, S, 14)
+    got = ctx.run("prj", R, S, radixBits=14)
+    assert got["prjPath"] == 0
+    assert (got["totalMatches"], got["prjChecksum"]) == (want["matches"], want["checksum"])
+    S = hj.generate_data("sorted", n)
+    want = oracle.prj_join(R, S, 14)
+    got = ctx.run("auto", R, S, radixBits=14)                   # a shuffled R has no locality: the radix join
+    assert got["algoUsed"] == "prj" and got["prjPath"] == 1
+    assert (got["totalMatches"], got["prjChecksum"]) == (want["matches"], want["checksum"])
+
+
 @pytest.mark.parametrize("nR,nS", [(40_000_000, 1 << 25), (1 << 25, 40_000_000)])
 def test_prj_unequal_sizes_across_the_chunk_length_step(nR, nS):
     """|R| and |S| on opposite sides of the size where the partitioning chunk length doubles: the smaller relation
