@@ -463,6 +463,7 @@ static int build_htm(hj_ctx* c, const uint64_t* dR, uint64_t rSize, uint64_t idx
     // buckets by one scan, fill them in index order, link
     HJ_HIP(c, hipMemcpyAsync(c->hCtr, c->dCtr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
     HJ_HIP(c, hipStreamSynchronize(c->stream));
+    fold_counter_shards(c->hCtr);
     const uint64_t conflicts = c->hCtr->conflicts;              // >= overflow buckets needed
     c->htmOverflowUsed = conflicts;
     if (conflicts) {
@@ -628,6 +629,7 @@ int hj_fetch_result(hj_ctx* c, hj_result* out)
     HJ_HIP(c, hipSetDevice(c->device));
     HJ_HIP(c, hipMemcpyAsync(c->hCtr, c->dCtr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
     HJ_HIP(c, hipStreamSynchronize(c->stream));
+    fold_counter_shards(c->hCtr);
     memset(out, 0, sizeof(*out));
     const Counters& k = *c->hCtr;
     out->rSize = c->rSize; out->sSize = c->sSize; out->tableSize = c->tableSize;
@@ -697,6 +699,7 @@ int hj_export_buckets(hj_ctx* c, void* host_buckets, uint64_t numBuckets, void* 
     HJ_HIP(c, hipSetDevice(c->device));
     HJ_HIP(c, hipMemcpyAsync(c->hCtr, c->dCtr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
     HJ_HIP(c, hipStreamSynchronize(c->stream));
+    fold_counter_shards(c->hCtr);
     const uint64_t used = c->hCtr->htmOverflowBuckets;
     if (nOverflow) *nOverflow = used;
     if (used && (!host_overflows || overflowCap < used + 1)) return fail(c, HJ_ERR_INVALID, "hj_export_buckets: overflow buffer too small");

@@ -408,13 +408,14 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
         loInv = a > loInv ? a : loInv; hi1 = b > hi1 ? b : hi1;
     }
     if (lane == 0) {
-        if (c0) atomicAdd(&ctr->conflicts, c0);
-        if (dropSum) atomicAdd(&ctr->conflictSum, dropSum);
-        if (inSum) atomicAdd(&ctr->inputSum, inSum);
-        if (c3 & 0xFFFFFFFFull) atomicAdd(&ctr->badKeys, c3 & 0xFFFFFFFFull);
-        if (c3 >> 32) atomicAdd(&ctr->foreign, c3 >> 32);
-        if (c4) atomicAdd(&ctr->deferred, c4);
-        if (hi1) { atomicMax(&ctr->usedLoInv, (unsigned long long)loInv); atomicMax(&ctr->usedHi1, (unsigned long long)hi1); }
+        Counters::Shard* const sh = counter_shard(ctr);
+        if (c0) atomicAdd(&sh->conflicts, c0);
+        if (dropSum) atomicAdd(&sh->conflictSum, dropSum);
+        if (inSum) atomicAdd(&sh->inputSum, inSum);
+        if (c3 & 0xFFFFFFFFull) atomicAdd(&sh->badKeys, c3 & 0xFFFFFFFFull);
+        if (c3 >> 32) atomicAdd(&sh->foreign, c3 >> 32);
+        if (c4) atomicAdd(&sh->deferred, c4);
+        if (hi1) { atomicMax(&sh->usedLoInv, (unsigned long long)loInv); atomicMax(&sh->usedHi1, (unsigned long long)hi1); }
     }
 }
 
@@ -424,10 +425,21 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
 // table end (probe walks wrap there) the whole table is made valid.
 __global__ void k_finalize_range(Counters* __restrict__ ctr, uint32_t numBlocks, uint64_t tableSize, Gate gate)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0 || gate_closed(gate)) return;
-    const unsigned long long hi1 = ctr->usedHi1;
+    if (blockIdx.x != 0 || threadIdx.x >= 64 || gate_closed(gate)) return;
+    // the two maxima: what was written directly + the 64 shards (hj_device.h, Counters), one shard per lane
+    static_assert(Counters::kShards == 64, "one shard per lane of the single wavefront this kernel runs as");
+    unsigned long long usedLoInvAll = ctr->shard[threadIdx.x & 63].usedLoInv, usedHi1All = ctr->shard[threadIdx.x & 63].usedHi1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long a = __shfl_xor(usedLoInvAll, off, 64), b = __shfl_xor(usedHi1All, off, 64);
+        usedLoInvAll = a > usedLoInvAll ? a : usedLoInvAll; usedHi1All = b > usedHi1All ? b : usedHi1All;
+    }
+    usedLoInvAll = ctr->usedLoInv > usedLoInvAll ? ctr->usedLoInv : usedLoInvAll;
+    usedHi1All = ctr->usedHi1 > usedHi1All ? ctr->usedHi1 : usedHi1All;
+    if (threadIdx.x != 0) return;
+    const unsigned long long hi1 = usedHi1All;
     if (hi1 == 0) { ctr->validLo = 0; ctr->validHiEx = 0; return; }          // nothing inserted anywhere
-    const unsigned long long lo = (unsigned long long)(uint32_t)~(uint32_t)ctr->usedLoInv;
+    const unsigned long long lo = (unsigned long long)(uint32_t)~(uint32_t)usedLoInvAll;
     const unsigned long long hiEx = hi1 + 1;                                   // blocks [lo, hi+1] probed
     if (hiEx + 1 >= numBlocks) { ctr->validLo = 0; ctr->validHiEx = tableSize; }
     else { ctr->validLo = lo << kBlkShift; ctr->validHiEx = hiEx << kBlkShift; }
@@ -500,8 +512,8 @@ k_build_deferred(const DeferredEntry* __restrict__ queue, const unsigned long lo
         dropSum += __shfl_down(dropSum, off, 64);
     }
     if ((threadIdx.x & 63) == 0) {
-        if (drops) atomicAdd(&ctr->conflicts, drops);
-        if (dropSum) atomicAdd(&ctr->conflictSum, dropSum);
+        if (drops) atomicAdd(&counter_shard(ctr)->conflicts, drops);
+        if (dropSum) atomicAdd(&counter_shard(ctr)->conflictSum, dropSum);
     }
 }
 

@@ -76,10 +76,11 @@ k_htm_build_global(const uint64_t* __restrict__ R, uint64_t n, uint32_t sliceLen
     if (threadIdx.x == 0) ccounts[blockIdx.x] = sCount;
     drops = htm_wave_sum(drops); dropSum = htm_wave_sum(dropSum); inSum = htm_wave_sum(inSum); bad = htm_wave_sum(bad);
     if ((threadIdx.x & 63) == 0) {
-        if (drops) atomicAdd(&ctr->conflicts, drops);
-        if (dropSum) atomicAdd(&ctr->conflictSum, dropSum);
-        if (inSum) atomicAdd(&ctr->inputSum, inSum);
-        if (bad) atomicAdd(&ctr->badKeys, bad);
+        Counters::Shard* const sh = counter_shard(ctr);
+        if (drops) atomicAdd(&sh->conflicts, drops);
+        if (dropSum) atomicAdd(&sh->conflictSum, dropSum);
+        if (inSum) atomicAdd(&sh->inputSum, inSum);
+        if (bad) atomicAdd(&sh->badKeys, bad);
     }
 }
 
@@ -180,7 +181,7 @@ k_htm_probe(const uint64_t* __restrict__ S, uint64_t n, const uint64_t* __restri
         }
     }
     matches = htm_wave_sum(matches);
-    if ((threadIdx.x & 63) == 0 && matches) atomicAdd(&ctr->matches, matches);
+    if ((threadIdx.x & 63) == 0 && matches) atomicAdd(&counter_shard(ctr)->matches, matches);
 }
 
 // ---- checksums (:322-342): tuples in primary buckets / in overflow buckets ------------------------------------------------

@@ -148,11 +148,12 @@ k_build_atomic_min(const void* __restrict__ Rv, uint64_t n, uint64_t* __restrict
             if (tail < n) build_one(R[tail], idxBase + tail, table, mask, hshift, probeLen, sc, drops, dropSum, inSum, bad);
         }
     }
-    flush_counter(&ctr->conflicts, drops);
-    flush_counter(&ctr->conflictSum, dropSum);
-    flush_counter(&ctr->inputSum, inSum);
-    flush_counter(&ctr->badKeys, bad & 0xFFFFFFFFull);
-    flush_counter(&ctr->foreign, bad >> 32);
+    Counters::Shard* const sh = counter_shard(ctr);
+    flush_counter(&sh->conflicts, drops);
+    flush_counter(&sh->conflictSum, dropSum);
+    flush_counter(&sh->inputSum, inSum);
+    flush_counter(&sh->badKeys, bad & 0xFFFFFFFFull);
+    flush_counter(&sh->foreign, bad >> 32);
 }
 
 void launch_build_atomic_min(const void* R, bool key32, uint64_t n, uint64_t* table, uint64_t tableSize, uint32_t hshift,
@@ -276,8 +277,8 @@ k_probe(const void* __restrict__ Sv, uint64_t n, const uint64_t* __restrict__ ta
         for (uint64_t i = 0; i < head; ++i) { matches += probe_one(S[i], table, mask, hshift, probeLen, validLo, validHiEx); foreign += is_foreign((uint32_t)S[i], sc); }
         for (uint64_t i = head + nv * EPV; i < n; ++i) { matches += probe_one(S[i], table, mask, hshift, probeLen, validLo, validHiEx); foreign += is_foreign((uint32_t)S[i], sc); }
     }
-    flush_counter(&ctr->matches, matches);
-    flush_counter(&ctr->foreign, foreign);
+    flush_counter(&counter_shard(ctr)->matches, matches);
+    flush_counter(&counter_shard(ctr)->foreign, foreign);
 }
 
 void launch_probe(const void* S, bool key32, uint64_t n, const uint64_t* table, uint64_t tableSize, uint32_t hshift,

@@ -893,8 +893,8 @@ k_prj_join(const uint32_t* __restrict__ partR, const uint32_t* __restrict__ offR
         checksum += __shfl_down(checksum, off, 64);
     }
     if ((threadIdx.x & 63) == 0) {
-        if (matches) atomicAdd(&ctr->prjMatches, matches);
-        if (checksum) atomicAdd(&ctr->prjChecksum, checksum);
+        if (matches) atomicAdd(&counter_shard(ctr)->prjMatches, matches);
+        if (checksum) atomicAdd(&counter_shard(ctr)->prjChecksum, checksum);
     }
     if (threadIdx.x == 0 && overflowParts) atomicAdd(&ctr->prjOverflowParts, (unsigned long long)overflowParts);
 }
