@@ -490,8 +490,10 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
 }
 
 // Phase B for the sliced deferred queue: chunk c's entries are queue[c * chunkLen .. + dcounts[c]). Same walk as
-// k_build_deferred (hj_build_own.hip): the probe walk of every deferred tuple finished with global atomics. One
-// wavefront per chunk slice at a time, slices dealt round-robin.
+// k_build_deferred (hj_build_own.hip): the probe walk of every deferred tuple finished with global atomics. The walks
+// are chains of dependent memory-side atomics (microseconds each), so the phase lasts as long as the longest sequence
+// one lane has to work through: a whole workgroup takes a slice at a time (a slice holds ~220 entries on `uniform` at
+// 2^30: every entry has its own lane at once; one wavefront per slice took four batches one after the other).
 template <bool HTM>
 __global__ void __launch_bounds__(kBlock)
 k_wave_deferred(const DeferredEntry* __restrict__ queue, const uint32_t* __restrict__ dcounts, uint32_t nChunks,
@@ -500,14 +502,12 @@ k_wave_deferred(const DeferredEntry* __restrict__ queue, const uint32_t* __restr
 {
     if (gate_closed(gate)) return;
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t nWaves = gridDim.x * (kBlock / 64), w0 = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     unsigned long long drops = 0, dropSum = 0;
-    for (uint32_t c = w0; c < nChunks; c += nWaves) {
+    for (uint32_t c = blockIdx.x; c < nChunks; c += gridDim.x) {
         const uint32_t cnt = dcounts[c];
         const DeferredEntry* q = queue + (uint64_t)c * chunkLen;
-        uint32_t cCount = HTM ? ccounts[c] : 0u;                       // this slice's conflicts so far (one wavefront per slice)
-        for (uint32_t i0 = 0; i0 < cnt; i0 += 64) {
-            const uint32_t i = i0 + lane;
+        for (uint32_t i0 = 0; i0 < cnt; i0 += kBlock) {
+            const uint32_t i = i0 + threadIdx.x;
             const bool has = i < cnt;
             uint64_t mine = has ? q[i].packed : 0ull;
             uint64_t pos = has ? q[i].pos : 0ull;
@@ -529,12 +529,17 @@ k_wave_deferred(const DeferredEntry* __restrict__ queue, const uint32_t* __restr
                 pos = (pos + 1) & mask;
             }
             if constexpr (HTM) {
+                // the slice's conflict list is appended to by four wavefronts now: one atomic per wavefront reserves the places
+                // (ccounts[c] holds what k_build_wave recorded; the list's order is free, the chain phase sorts by index)
                 const unsigned long long cm = __ballot(dropped);
-                if (dropped) htmConflicts[(uint64_t)c * chunkLen + cCount + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull))] = mine;
-                cCount += (uint32_t)__popcll(cm);
+                if (cm) {
+                    uint32_t base = 0;
+                    if (lane == (uint32_t)__ffsll((long long)cm) - 1u) base = atomicAdd(&ccounts[c], (uint32_t)__popcll(cm));
+                    base = (uint32_t)__shfl((int)base, __ffsll((long long)cm) - 1, 64);
+                    if (dropped) htmConflicts[(uint64_t)c * chunkLen + base + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull))] = mine;
+                }
             }
         }
-        if (HTM && lane == 0) ccounts[c] = cCount;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -659,7 +664,7 @@ hipError_t launch_build_wave(const void* R, bool key32, uint64_t n, uint32_t hsh
     if (!(parts & 2)) return hipSuccess;
     hipLaunchKernelGGL(k_wave_finalize_range, dim3(1), dim3(64), 0, s, ctr, tableSize, gate);
     hipLaunchKernelGGL(k_wave_fill_edges, dim3(2048), dim3(kBlock), 0, s, table, ctr, tableSize, gate);
-    const dim3 gDef((nChunks + kBlock / 64 - 1) / (kBlock / 64));
+    const dim3 gDef(nChunks);                                  // one workgroup per slice
     if (htm) hipLaunchKernelGGL(k_wave_deferred<true>, gDef, dim3(kBlock), 0, s, static_cast<const DeferredEntry*>(queueBuf), dcounts,
                                 nChunks, sliceLen, table, tableSize - 1, hshift, probeLen, ctr, gate, htmConflicts, ccounts);
     else hipLaunchKernelGGL(k_wave_deferred<false>, gDef, dim3(kBlock), 0, s, static_cast<const DeferredEntry*>(queueBuf), dcounts,

@@ -310,7 +310,7 @@ k_radix_scatter(const void* __restrict__ in, void* __restrict__ outv, PassParams
     constexpr int E = (int)EPV * TV;                 // elements per thread per tile
     constexpr uint32_t TILE = (uint32_t)NT * E;
     static_assert(!PF || E == 16, "vmcnt immediate below assumes 16 stores per thread per full tile");
-    static_assert(TILE <= 65536, "rank is kept in 16 bits");
+    static_assert(TILE <= 65536 && E % 2 == 0, "ranks are kept in 16 bits, two to a register");
     using OutT = typename std::conditional<OUT32, uint32_t, uint64_t>::type;
     OutT* __restrict__ out = static_cast<OutT*>(outv);
 
@@ -467,6 +467,17 @@ k_radix_scatter(const void* __restrict__ in, void* __restrict__ outv, PassParams
 //   No atomics, no scan, no second read: 12 B (pass 1) and 8 B (pass 2) per tuple instead of 20 and 12.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kMaxInFrags = 1024;     // pass-1 fragments one pass-2 chunk may span (C1 <= 1024)
+// workgroup geometry of the two passes: threads, elements per thread and tile, waves per SIMD the registers must allow
+#ifndef HJ_FRAG1_NT
+#define HJ_FRAG1_NT 1024
+#define HJ_FRAG1_E 32
+#define HJ_FRAG1_WPE 4
+#endif
+#ifndef HJ_FRAG2_NT
+#define HJ_FRAG2_NT 512
+#define HJ_FRAG2_E 16
+#define HJ_FRAG2_WPE 4
+#endif
 
 struct FragPass {
     uint32_t C;              // chunks per input segment = fragments per output partition
@@ -480,13 +491,12 @@ struct FragPass {
     const uint32_t* inCnt;
 };
 
-template <bool IN32, int NT>
-__global__ void __launch_bounds__(NT, 4)
+template <bool IN32, int NT, int E = 16, int WPE = 4>         // E = elements per thread and tile
+__global__ void __launch_bounds__(NT, WPE)
 k_radix_scatter_frag(const void* __restrict__ in, uint32_t* __restrict__ out, FragPass p, Counters* __restrict__ ctr)
 {
-    constexpr int E = 16;                                     // elements per thread and tile
     constexpr uint32_t TILE = (uint32_t)NT * E;
-    static_assert(TILE <= 65536, "rank is kept in 16 bits");
+    static_assert(TILE <= 65536 && E % 2 == 0, "ranks are kept in 16 bits, two to a register");
     constexpr uint32_t kPadShift = 5;                         // see k_radix_scatter
     constexpr uint32_t kDump = TILE + (TILE >> kPadShift);
     __shared__ uint32_t stage[kDump + 1];
@@ -536,28 +546,35 @@ k_radix_scatter_frag(const void* __restrict__ in, uint32_t* __restrict__ out, Fr
     if (threadIdx.x == 0) sAbort = 0;
     __syncthreads();
 
-    const uint4* in4 = reinterpret_cast<const uint4*>(in);
     const uint32_t* in1 = reinterpret_cast<const uint32_t*>(in);
-    const uint32_t lastVec = (begin + total - 1) / 2;          // pass 1: last 16-byte vector holding a tuple of the chunk
-    const uint32_t b0 = begin & ~1u;
     uint32_t fA = 0;                                            // pass 2: input fragment the tile starts in
     uint32_t tileNo = 0;
-    for (uint32_t T = 0; T < total + (IN32 ? 0u : begin - b0); T += TILE, ++tileNo) {
+    for (uint32_t T = 0; T < total; T += TILE, ++tileNo) {
+        // the thread index is made opaque per tile: everything derived from it (16 positions, LDS addresses, offsets) is
+        // one add away, and hoisted out of the loop it only fills registers until they spill
+        uint32_t tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
         uint32_t tv[E], okMask = 0;
         if constexpr (!IN32) {
-            // 8 vectors of two tuples per thread; the tile starts at the even tuple b0 + T
-            uint4 cur[E / 2];
+            // one register per element instead of two (the payload word is never looked at, as in mc: the partition
+            // function and the join read tuple_t.key only); lanes read every second word of contiguous lines
+            // (a chunk is at most 2^21 tuples -- frag_geometry --, so byte offsets from the chunk's base fit 32 bits:
+            // scalar base + one offset register per load)
+            const char* const base = static_cast<const char*>(in) + 8ull * (begin + T);
+            if (T + TILE <= total) {                            // a full tile: scalar base per load, one shared offset register
 #pragma unroll
-            for (int k = 0; k < E / 2; ++k) {
-                const uint32_t v = (b0 + T) / 2 + (uint32_t)k * NT + threadIdx.x;
-                cur[k] = in4[v < lastVec ? v : lastVec];
-            }
-            const uint32_t rel0 = b0 + T - begin + 2 * threadIdx.x;   // wraps (= huge) before `begin`
+                for (int j = 0; j < E; ++j)
+                    tv[j] = *reinterpret_cast<const uint32_t*>(base + (size_t)j * NT * 8 + (tid << 3));
+                okMask = E == 32 ? 0xFFFFFFFFu : (1u << (E & 31)) - 1u;
+            } else {
+                const uint32_t left = total - T;                // >= 1
 #pragma unroll
-            for (int k = 0; k < E / 2; ++k) {
-                const uint32_t rel = rel0 + 2u * (uint32_t)k * NT;
-                tv[2 * k] = cur[k].x; tv[2 * k + 1] = cur[k].z;
-                okMask |= (rel < total ? 1u : 0u) << (2 * k) | (rel + 1 < total ? 1u : 0u) << (2 * k + 1);
+                for (int j = 0; j < E; ++j) {
+                    const uint32_t d = (uint32_t)j * NT + tid;
+                    const bool ok = d < left;
+                    tv[j] = *reinterpret_cast<const uint32_t*>(base + ((ok ? d : left - 1) << 3));
+                    okMask |= (ok ? 1u : 0u) << j;
+                }
             }
         } else {
             // element d of the chunk lives in input fragment f (prefix[f] <= d < prefix[f+1]) at slot d - prefix[f].
@@ -573,7 +590,7 @@ k_radix_scatter_frag(const void* __restrict__ in, uint32_t* __restrict__ out, Fr
             }
 #pragma unroll
             for (int j = 0; j < E; ++j) {
-                const uint32_t d = T + (uint32_t)j * NT + threadIdx.x;
+                const uint32_t d = T + (uint32_t)j * NT + tid;
                 const bool ok = d < total;
                 uint32_t at = d + (d >= bound[2] ? start[3] : d >= bound[1] ? start[2] : d >= bound[0] ? start[1] : start[0]);
                 if (ok && d >= bound[3]) {
@@ -586,16 +603,17 @@ k_radix_scatter_frag(const void* __restrict__ in, uint32_t* __restrict__ out, Fr
             }
         }
         // ---- rank ----
-        uint32_t br[E];
+        uint32_t rk[E / 2];                                     // two 16-bit ranks per register; the bin is recomputed from the key
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             const uint32_t bin = (tv[j] >> p.shift) & fmask;
-            br[j] = (bin << 16) | atomicAdd(&tileCnt[bin], (okMask >> j) & 1u);
+            const uint32_t r = atomicAdd(&tileCnt[bin], (okMask >> j) & 1u);
+            if (j & 1) rk[j / 2] |= r << 16; else rk[j / 2] = r;
         }
         __syncthreads();
         // ---- one wavefront: scan of the counters, cursors, capacity check ----
-        if (threadIdx.x < 64) {
-            const uint32_t b4 = 4 * threadIdx.x;
+        if (tid < 64) {
+            const uint32_t b4 = 4 * tid;
             uint32_t cnt[4], sum = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { cnt[j] = tileCnt[b4 + j]; tileCnt[b4 + j] = 0; sum += cnt[j]; }
@@ -603,7 +621,7 @@ k_radix_scatter_frag(const void* __restrict__ in, uint32_t* __restrict__ out, Fr
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
                 const uint32_t n = __shfl_up(inc, off, 64);
-                if ((int)threadIdx.x >= off) inc += n;
+                if ((int)tid >= off) inc += n;
             }
             uint32_t ex = inc - sum;
             bool over = false;
@@ -619,33 +637,35 @@ k_radix_scatter_frag(const void* __restrict__ in, uint32_t* __restrict__ out, Fr
             // someone else's overflow: looked at every 16th tile (one wave-uniform load of a word nobody writes otherwise)
             bool stop = __any(over);
             if (!stop && (tileNo & 15u) == 15u) stop = *reinterpret_cast<volatile unsigned long long*>(&ctr->prjFallback) != 0;
-            if (threadIdx.x == 63) { sValid = inc; if (stop) sAbort = 1; }
-            if (threadIdx.x == 0 && __any(over)) atomicExch(&ctr->prjFallback, 1ull);
+            if (tid == 63) { sValid = inc; if (stop) sAbort = 1; }
+            if (tid == 0 && __any(over)) atomicExch(&ctr->prjFallback, 1ull);
         }
         __syncthreads();
         if (sAbort) return;                                     // nothing of this path is used any more
         // ---- stage ----
 #pragma unroll
         for (int k = 0; k < E; ++k) {
-            const uint32_t at = tileOff[br[k] >> 16] + (br[k] & 0xFFFFu);
+            const uint32_t at = tileOff[(tv[k] >> p.shift) & fmask] + ((rk[k / 2] >> (16 * (k & 1))) & 0xFFFFu);
             stage[((okMask >> k) & 1u) ? at + (at >> kPadShift) : kDump] = tv[k];
         }
         __syncthreads();
         // ---- contiguous runs to HBM ----
         const uint32_t valid = sValid;
-        auto emit = [&](uint32_t q) {
-            const uint32_t t = stage[q + (q >> kPadShift)];
-            out[delta[(t >> p.shift) & fmask] + q] = t;
+        // staged position q = k * NT + thread lives at q + (q >> 5) = (thread + (thread >> 5)) + k * (NT + NT / 32): one
+        // address register and an immediate per k
+        static_assert(NT % 32 == 0, "the pad of a staged position splits into a thread part and a k part");
+        const uint32_t* const myStage = stage + (tid + (tid >> kPadShift));
+        auto emit = [&](int k) {
+            const uint32_t t = myStage[k * (NT + (NT >> kPadShift))];
+            out[delta[(t >> p.shift) & fmask] + (uint32_t)k * NT + tid] = t;
         };
         if (valid == TILE) {
 #pragma unroll
-            for (int k = 0; k < E; ++k) emit((uint32_t)k * NT + threadIdx.x);
+            for (int k = 0; k < E; ++k) emit(k);
         } else {
 #pragma unroll
-            for (int k = 0; k < E; ++k) {
-                const uint32_t q = (uint32_t)k * NT + threadIdx.x;
-                if (q < valid) emit(q);
-            }
+            for (int k = 0; k < E; ++k)
+                if ((uint32_t)k * NT + tid < valid) emit(k);
         }
     }
     __syncthreads();
@@ -1099,10 +1119,10 @@ hipError_t partition_relation_frag(const PrjPlan& pl, const PrjFrag& g, const Wo
     const uint32_t F1 = 1u << pl.bits1, F2 = 1u << pl.bits2;
     const FragPass p1{g.C1, 0u, F1, g.cap1, w.cnt1, (uint32_t)n, g.chunkLen1, 0u, 0u, nullptr};
     if (evS0) (void)hipEventRecord(evS0, s);
-    hipLaunchKernelGGL((k_radix_scatter_frag<false, 512>), dim3(g.C1), dim3(512), 0, s, static_cast<const void*>(in), tmp, p1, ctr);
+    hipLaunchKernelGGL((k_radix_scatter_frag<false, HJ_FRAG1_NT, HJ_FRAG1_E, HJ_FRAG1_WPE>), dim3(g.C1), dim3(HJ_FRAG1_NT), 0, s, static_cast<const void*>(in), tmp, p1, ctr);
     if (evS1) (void)hipEventRecord(evS1, s);
     const FragPass p2{g.C2, pl.bits1, F2, g.cap2, cnt2, 0u, 0u, g.C1 / g.C2, g.cap1, w.cnt1};
-    hipLaunchKernelGGL((k_radix_scatter_frag<true, 512>), dim3(F1 * g.C2), dim3(512), 0, s, static_cast<const void*>(tmp), out, p2, ctr);
+    hipLaunchKernelGGL((k_radix_scatter_frag<true, HJ_FRAG2_NT, HJ_FRAG2_E, HJ_FRAG2_WPE>), dim3(F1 * g.C2), dim3(HJ_FRAG2_NT), 0, s, static_cast<const void*>(tmp), out, p2, ctr);
     return hipGetLastError();
 }
 }  // namespace
