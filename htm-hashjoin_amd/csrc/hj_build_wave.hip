@@ -53,6 +53,12 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 #ifndef HJ_WV_PF
 #define HJ_WV_PF 1
 #endif
+#ifndef HJ_WV_WPE
+#define HJ_WV_WPE 4                                 // wavefronts per SIMD the registers must allow (16 per CU: what the rings' LDS allows)
+#endif
+#ifndef HJ_WV_WAVES_PER_CU
+#define HJ_WV_WAVES_PER_CU 16                       // chunks = resident wavefronts: one round of workgroups, no tail
+#endif
 #ifndef HJ_WV_CARRY
 #define HJ_WV_CARRY 1                               // 1: leave < 64 retry entries queued across tiles
 #endif
@@ -181,7 +187,7 @@ k_wave_bounds_scan(const uint32_t* __restrict__ raw, uint32_t nChunks, uint32_t 
 
 // ---- the build ------------------------------------------------------------------------------------------------
 template <bool KEY32, bool CHECK, bool HTM>
-__global__ void __launch_bounds__(kWvThreads, 4)
+__global__ void __launch_bounds__(kWvThreads, HJ_WV_WPE)
 k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_t nChunks, const uint32_t* __restrict__ starts,
              const uint32_t* __restrict__ bounds, uint64_t* __restrict__ table, uint64_t mask, uint32_t hshift,
              uint32_t probeLen, uint64_t idxBase, ShardCheck sc, DeferredEntry* __restrict__ queue,
@@ -600,7 +606,7 @@ k_wave_fill_edges(uint64_t* __restrict__ table, const Counters* __restrict__ ctr
 // ---- host side ----------------------------------------------------------------------------------------------------
 size_t wave_lds_bytes() { return kWvLdsBytes; }
 bool wave_supported(uint64_t tableSize) { return tableSize >= (uint64_t)kWvWin; }
-uint32_t wave_max_chunks(int nCU) { return 16u * (uint32_t)nCU; }
+uint32_t wave_max_chunks(int nCU) { return (uint32_t)HJ_WV_WAVES_PER_CU * (uint32_t)nCU; }
 size_t wave_bounds_bytes(int nCU) { return (5 * (size_t)wave_max_chunks(nCU) + 4) * sizeof(uint32_t); }   // raw, bounds (+1), starts (+1), dcounts, ccounts
 static uint64_t wave_chunk_len(uint64_t n, int nCU)
 {

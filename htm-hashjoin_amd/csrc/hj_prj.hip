@@ -578,27 +578,23 @@ k_radix_scatter_frag(const void* __restrict__ in, uint32_t* __restrict__ out, Fr
             }
         } else {
             // element d of the chunk lives in input fragment f (prefix[f] <= d < prefix[f+1]) at slot d - prefix[f].
-            // A tile of 8192 elements meets few fragments: the first four are resolved by compares against
-            // wave-uniform bounds, anything beyond (tiny fragments) by a search.
+            // A thread's elements d = T + j * NT + thread grow with j, so it walks the fragments once per tile: the
+            // current fragment's end and address offset stay in registers, and a step to the next fragment (a tile of
+            // 32768 keys meets ~8 fragments of 4096) costs two LDS reads.
             while (fA + 1 < p.inFrags && prefix[fA + 1] <= T) ++fA;
-            uint32_t bound[4], start[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t f = fA + k < p.inFrags ? fA + k : p.inFrags - 1;
-                start[k] = (firstFrag + f) * p.inCap - prefix[f];
-                bound[k] = fA + k + 1 < p.inFrags ? prefix[fA + k + 1] : 0xFFFFFFFFu;
-            }
+            uint32_t f = fA;
+            uint32_t bound = f + 1 < p.inFrags ? prefix[f + 1] : 0xFFFFFFFFu;
+            uint32_t off = (firstFrag + f) * p.inCap - prefix[f];
 #pragma unroll
             for (int j = 0; j < E; ++j) {
                 const uint32_t d = T + (uint32_t)j * NT + tid;
                 const bool ok = d < total;
-                uint32_t at = d + (d >= bound[2] ? start[3] : d >= bound[1] ? start[2] : d >= bound[0] ? start[1] : start[0]);
-                if (ok && d >= bound[3]) {
-                    uint32_t f = fA + 4;
-                    while (f + 1 < p.inFrags && d >= prefix[f + 1]) ++f;
-                    at = (firstFrag + f) * p.inCap + d - prefix[f];
+                while (ok && d >= bound) {
+                    ++f;
+                    bound = f + 1 < p.inFrags ? prefix[f + 1] : 0xFFFFFFFFu;
+                    off = (firstFrag + f) * p.inCap - prefix[f];
                 }
-                tv[j] = in1[ok ? at : firstFrag * p.inCap];
+                tv[j] = in1[ok ? d + off : firstFrag * p.inCap];
                 okMask |= (ok ? 1u : 0u) << j;
             }
         }
