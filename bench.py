@@ -3,8 +3,9 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--log2n 30] [--dist uniform]
 
-One "step" = one pass of the hot path over one batch: clear table -> build(R) -> probe(S)
-with R and S already resident in HBM (DataGen inputs, generated on the host and copied
+One "step" = one pass of the hot path over one batch: build(R) -> probe(S) (the build writes
+every reachable table slot once, empties included: there is no separate clear) with R and S
+already resident in HBM (DataGen inputs, generated on the host and copied
 in before the timed region). N=1 workload: |R| = |S| = 2^30 uint32-key tuples, `uniform`
 (BASELINE.json metric; configs[1]'s operator at the metric's size). For N > 1 (launched
 with torch.distributed.run, one rank per GPU) every rank holds its own 2^log2n tuples of
