@@ -59,6 +59,9 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 #ifndef HJ_WV_WAVES_PER_CU
 #define HJ_WV_WAVES_PER_CU 16                       // chunks = resident wavefronts: one round of workgroups, no tail
 #endif
+#ifndef HJ_WV_ALLIN
+#define HJ_WV_ALLIN 1                               // 1: tiles wholly inside ring and range skip the per-tuple ring test
+#endif
 #ifndef HJ_WV_CARRY
 #define HJ_WV_CARRY 1                               // 1: leave < 64 retry entries queued across tiles
 #endif
@@ -393,12 +396,20 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
                 bad += (in & !okKey) ? 1u : 0u;
                 if constexpr (CHECK) foreign += (in & is_foreign(klo[j], sc)) ? 1u : 0u;
                 liveMask |= ok ? (1u << j) : 0u;
-                myMin = (ok & (home[j] < myMin)) ? home[j] : myMin;
-                myMaxInv = (ok & (~home[j] < myMaxInv)) ? ~home[j] : myMaxInv;
+                if constexpr (FULL && HJ_WV_ALLIN) {
+                    // full tiles take the bounds over every tuple, valid or not: an invalid key (the build fails with
+                    // HJ_ERR_KEY_RANGE anyway) can only make the ring move less, and every access stays guarded
+                    myMin = home[j] < myMin ? home[j] : myMin;
+                    myMaxInv = ~home[j] < myMaxInv ? ~home[j] : myMaxInv;
+                } else {
+                    myMin = (ok & (home[j] < myMin)) ? home[j] : myMin;
+                    myMaxInv = (ok & (~home[j] < myMaxInv)) ? ~home[j] : myMaxInv;
+                }
             }
         };
         if (full) classify(std::true_type{}); else classify(std::false_type{});
         const uint32_t tmin = wave_umin(myMin);                       // kNone: the tile holds no valid tuple
+        bool allIn = false;                                           // wave-uniform: every home slot of the tile lies in ring and range
         if (tmin != kNone) {
             // The ring moves only as far as it must for the tile's highest home slot (+ a probe walk) to fit, so it
             // keeps as much history as it can: retry entries carried over from the previous tile are still inside.
@@ -410,20 +421,31 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
             target = target < gmin ? target : gmin;
             target = target < limG ? target : limG;
             advance(target);
+            if (HJ_WV_ALLIN) {
+                const uint32_t gmax = tmax >> kGranShift;
+                allIn = full & (gmin - winLoG < kWvGran) & (gmax - winLoG < kWvGran) & (gmax < limG);
+            }
         }
 
         // ---- the PER home-slot attempts of the tile, issued together (independent LDS round trips) ----
         unsigned long long oldv[kWvPer];
         uint32_t ownMask = 0;
+        // (when the tile's lowest and highest home slot are inside ring and range -- nearly every full tile -- the
+        // per-tuple test is skipped: the retry rounds leave the VALU little to spare, hj DESIGN 4.2)
+        auto attempts = [&](auto allTag) {
+            constexpr bool ALL = decltype(allTag)::value;
 #pragma unroll
-        for (int j = 0; j < kWvPer; ++j) {
-            const bool own = ((liveMask >> j) & 1u) & in_ring(home[j]);
-            ownMask |= own ? (1u << j) : 0u;
-            oldv[j] = kEmpty;
-            if (own)
-                oldv[j] = atomicMin(reinterpret_cast<unsigned long long*>(&win[home[j] & (kWvWin - 1)]),
-                                    (unsigned long long)wv_pack(idx0 + tb + lane + 64 * j, klo[j]));
-        }
+            for (int j = 0; j < kWvPer; ++j) {
+                const bool own = ((liveMask >> j) & 1u) & (ALL || in_ring(home[j]));
+                if constexpr (!ALL) ownMask |= own ? (1u << j) : 0u;
+                oldv[j] = kEmpty;
+                if (own)
+                    oldv[j] = atomicMin(reinterpret_cast<unsigned long long*>(&win[home[j] & (kWvWin - 1)]),
+                                        (unsigned long long)wv_pack(idx0 + tb + lane + 64 * j, klo[j]));
+            }
+            if constexpr (ALL) ownMask = liveMask;
+        };
+        if (allIn) attempts(std::true_type{}); else attempts(std::false_type{});
         // ---- whatever did not finish goes to the retry queue, compacted ----
 #pragma unroll
         for (int j = 0; j < kWvPer; ++j) {
