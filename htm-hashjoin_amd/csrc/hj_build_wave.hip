@@ -84,6 +84,13 @@ constexpr size_t kWvLdsBytes = (size_t)kWvWaves * (kWvWin * sizeof(uint64_t) + 3
 
 __device__ __forceinline__ uint64_t wv_pack(uint32_t hi, uint32_t lo) { return ((uint64_t)hi << 32) | lo; }
 
+// a lane's rank among the lanes of a ballot: v_mbcnt_lo + v_mbcnt_hi (the mask stays in SGPRs) instead of two ANDs with a
+// per-lane "lanes below me" mask and two popcounts
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 // minimum over the wavefront, result wave-uniform: four DPP steps inside each row of 16, then the four rows
 __device__ __forceinline__ uint32_t wave_umin(uint32_t v)
 {
@@ -213,6 +220,7 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
     const uint32_t plen = (uint32_t)((cb + clen + kWvOverlap < n ? cb + clen + kWvOverlap : n) - cb);
     const uint32_t mask32 = (uint32_t)mask;
     const uint32_t numGran = (uint32_t)((mask + 1) >> kGranShift);
+    if constexpr (!KEY32) hshift = 0u;            // 8-byte tuples always hash with shift 0 (launch_build_wave checks): one shift less per home slot
     using Elem = typename std::conditional<KEY32, uint32_t, uint64_t>::type;
     const Elem* __restrict__ Rc = static_cast<const Elem*>(Rv) + cb;
     const uint32_t idx0 = (uint32_t)(idxBase + cb);
@@ -294,7 +302,7 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
         if constexpr (HTM) {       // the bucket is full: the tuple is one of the reference's conflicts (HTMHashBuild.hpp:181-183)
             const unsigned long long cm = __ballot(dropped);
             if (cm) {
-                if (dropped) myConflicts[cCount + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull))] = mine;
+                if (dropped) myConflicts[cCount + lane_rank(cm)] = mine;
                 cCount += (uint32_t)__popcll(cm);
             }
         }
@@ -304,7 +312,7 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
         const unsigned long long dm = __ballot(toDefer);
         if (dm) {
             if (toDefer) {
-                DeferredEntry* q = myDeferred + dCount + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull));
+                DeferredEntry* q = myDeferred + dCount + lane_rank(dm);
                 q->pos = pos; q->packed = mine;
                 const uint32_t db = pos >> 9;
                 usedLo = db < usedLo ? db : usedLo; usedHi1 = db + 1 > usedHi1 ? db + 1 : usedHi1;
@@ -329,7 +337,7 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
         const bool again = round_body(pos, mlo, mhi, has);
         const unsigned long long am = __ballot(again);
         if (again) {
-            const uint32_t at = (qHead + qCount + (uint32_t)__popcll(am & ((1ull << lane) - 1ull))) & (kWvQCap - 1);
+            const uint32_t at = (qHead + qCount + lane_rank(am)) & (kWvQCap - 1);
             myQPos[at] = pos; myQLo[at] = mlo; myQHi[at] = mhi;
         }
         qCount += (uint32_t)__popcll(am);
@@ -375,10 +383,15 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
         issue(nxt[p], tb + kWvPf * kWvTile);
         const uint32_t roundsAtTileStart = rounds;
         (void)roundsAtTileStart;
-        uint32_t liveMask = 0, myMin = kNone, myMaxInv = kNone;       // max kept as min of the complement
+        uint32_t myMin = kNone, myMaxInv = kNone;                     // max kept as min of the complement
         uint32_t home[kWvPer];
+        // per row: "a tuple this wavefront inserts" / "... and whose home slot it may touch now". Kept as one boolean per
+        // row -- a lane mask in a scalar register pair, free to produce and to branch on -- not as bits of a per-lane word
+        // (two VALU instructions per tuple to pack, two to unpack, in a kernel whose retry rounds are VALU bound)
+        bool live[kWvPer], own[kWvPer];
         // FULL tiles (every position is this chunk's own, no seam zone) skip the zone tests: they are all but the
         // first and the last one or two tiles of a chunk
+        uint32_t badTile = 0;                                         // wave-uniform: invalid tuples of a full tile
         auto classify = [&](auto fullTag) {
             constexpr bool FULL = decltype(fullTag)::value;
 #pragma unroll
@@ -393,9 +406,10 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
                                                         : ((o < plen) & !lastChunk & (home[j] < limSlot)));
                 const bool ok = mineHere & okKey;
                 inSum += in ? (unsigned long long)wv_pack(khi[j], klo[j]) : 0ull;
-                bad += (in & !okKey) ? 1u : 0u;
+                if constexpr (FULL) badTile += 64u - (uint32_t)__popcll(__ballot(okKey));     // scalar: no per-lane count
+                else bad += (in & !okKey) ? 1u : 0u;
                 if constexpr (CHECK) foreign += (in & is_foreign(klo[j], sc)) ? 1u : 0u;
-                liveMask |= ok ? (1u << j) : 0u;
+                live[j] = ok;
                 if constexpr (FULL && HJ_WV_ALLIN) {
                     // full tiles take the bounds over every tuple, valid or not: an invalid key (the build fails with
                     // HJ_ERR_KEY_RANGE anyway) can only make the ring move less, and every access stays guarded
@@ -408,6 +422,7 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
             }
         };
         if (full) classify(std::true_type{}); else classify(std::false_type{});
+        bad += lane == 0 ? badTile : 0u;
         const uint32_t tmin = wave_umin(myMin);                       // kNone: the tile holds no valid tuple
         bool allIn = false;                                           // wave-uniform: every home slot of the tile lies in ring and range
         if (tmin != kNone) {
@@ -429,39 +444,36 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
 
         // ---- the PER home-slot attempts of the tile, issued together (independent LDS round trips) ----
         unsigned long long oldv[kWvPer];
-        uint32_t ownMask = 0;
         // (when the tile's lowest and highest home slot are inside ring and range -- nearly every full tile -- the
         // per-tuple test is skipped: the retry rounds leave the VALU little to spare, hj DESIGN 4.2)
         auto attempts = [&](auto allTag) {
             constexpr bool ALL = decltype(allTag)::value;
 #pragma unroll
             for (int j = 0; j < kWvPer; ++j) {
-                const bool own = ((liveMask >> j) & 1u) & (ALL || in_ring(home[j]));
-                if constexpr (!ALL) ownMask |= own ? (1u << j) : 0u;
+                own[j] = live[j] & (ALL || in_ring(home[j]));
                 oldv[j] = kEmpty;
-                if (own)
+                if (own[j])
                     oldv[j] = atomicMin(reinterpret_cast<unsigned long long*>(&win[home[j] & (kWvWin - 1)]),
                                         (unsigned long long)wv_pack(idx0 + tb + lane + 64 * j, klo[j]));
             }
-            if constexpr (ALL) ownMask = liveMask;
         };
         if (allIn) attempts(std::true_type{}); else attempts(std::false_type{});
         // ---- whatever did not finish goes to the retry queue, compacted ----
 #pragma unroll
         for (int j = 0; j < kWvPer; ++j) {
             while (qCount >= kWvRoundAt) retry_round();                // dense rounds; leaves room for one full step
-            const bool lv = (liveMask >> j) & 1u, own = (ownMask >> j) & 1u;
+            const bool lv = live[j], ow = own[j];
             uint32_t mlo = klo[j], mhi = idx0 + tb + lane + 64 * j;
             const uint64_t mine = wv_pack(mhi, mlo);
-            const bool fail = own & (oldv[j] != kEmpty);               // the slot was taken
+            const bool fail = ow & (oldv[j] != kEmpty);                // the slot was taken
             const bool disp = fail & (oldv[j] > mine);                 // ... by a later tuple: it moves on instead
             mlo = disp ? (uint32_t)oldv[j] : mlo; mhi = disp ? (uint32_t)(oldv[j] >> 32) : mhi;
             const uint32_t pos = fail ? ((home[j] + 1) & mask32) : home[j];
-            const bool again = fail | (lv & !own);                     // outside ring or range: the retry round defers it
+            const bool again = fail | (lv & !ow);                      // outside ring or range: the retry round defers it
             const unsigned long long am = __ballot(again);
             if (am) {
                 if (again) {
-                    const uint32_t at = (qHead + qCount + (uint32_t)__popcll(am & ((1ull << lane) - 1ull))) & (kWvQCap - 1);
+                    const uint32_t at = (qHead + qCount + lane_rank(am)) & (kWvQCap - 1);
                     myQPos[at] = pos; myQLo[at] = mlo; myQHi[at] = mhi;
                 }
                 qCount += (uint32_t)__popcll(am);
@@ -564,7 +576,7 @@ k_wave_deferred(const DeferredEntry* __restrict__ queue, const uint32_t* __restr
                     uint32_t base = 0;
                     if (lane == (uint32_t)__ffsll((long long)cm) - 1u) base = atomicAdd(&ccounts[c], (uint32_t)__popcll(cm));
                     base = (uint32_t)__shfl((int)base, __ffsll((long long)cm) - 1, 64);
-                    if (dropped) htmConflicts[(uint64_t)c * chunkLen + base + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull))] = mine;
+                    if (dropped) htmConflicts[(uint64_t)c * chunkLen + base + lane_rank(cm)] = mine;
                 }
             }
         }
@@ -660,6 +672,7 @@ hipError_t launch_build_wave(const void* R, bool key32, uint64_t n, uint32_t hsh
 {
     const bool htm = htmConflicts != nullptr;
     if (htm && (key32 || probeLen != 3 || sc.mask)) return hipErrorInvalidValue;
+    if (!key32 && hshift) return hipErrorInvalidValue;         // the kernel's tuple instances assume it
     const uint32_t maxChunks = wave_max_chunks(nCU);
     const uint64_t chunkLen = wave_chunk_len(n, nCU);
     static_assert(kWvTile * 4 > (int)(kWvLook + kWvOverlap), "a seam may move by less than the shortest chunk");
