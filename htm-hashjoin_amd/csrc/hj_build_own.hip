@@ -173,7 +173,7 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
             if (lane == 0) base = atomicAdd(queueCount, (unsigned long long)__popcll(dm));
             base = __shfl(base, 0, 64);
             if (toDefer) {
-                const unsigned long long at = base + __popcll(dm & ((1ull << lane) - 1ull));
+                const unsigned long long at = base + lane_rank(dm);
                 queue[at].pos = pos; queue[at].packed = mine;
                 deferred += 1;
                 const uint32_t db = pos >> kBlkShift;
@@ -196,7 +196,7 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
         const bool again = round_body(pos, mlo, mhi, has);
         const unsigned long long am = __ballot(again);
         if (again) {
-            const uint32_t at = qCount + (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
+            const uint32_t at = qCount + lane_rank(am);
             myQPos[at] = pos; myQLo[at] = mlo; myQHi[at] = mhi;
         }
         qCount += (uint32_t)__popcll(am);
@@ -369,7 +369,7 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
             const unsigned long long am = __ballot(again);
             if (am) {
                 if (again) {
-                    const uint32_t at = qCount + (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
+                    const uint32_t at = qCount + lane_rank(am);
                     myQPos[at] = pos; myQLo[at] = mlo; myQHi[at] = mhi;
                 }
                 qCount += (uint32_t)__popcll(am);

@@ -84,13 +84,6 @@ constexpr size_t kWvLdsBytes = (size_t)kWvWaves * (kWvWin * sizeof(uint64_t) + 3
 
 __device__ __forceinline__ uint64_t wv_pack(uint32_t hi, uint32_t lo) { return ((uint64_t)hi << 32) | lo; }
 
-// a lane's rank among the lanes of a ballot: v_mbcnt_lo + v_mbcnt_hi (the mask stays in SGPRs) instead of two ANDs with a
-// per-lane "lanes below me" mask and two popcounts
-__device__ __forceinline__ uint32_t lane_rank(unsigned long long m)
-{
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-
 // minimum over the wavefront, result wave-uniform: four DPP steps inside each row of 16, then the four rows
 __device__ __forceinline__ uint32_t wave_umin(uint32_t v)
 {

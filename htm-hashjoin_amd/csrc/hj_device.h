@@ -33,6 +33,18 @@ __host__ __device__ inline uint32_t home32(uint32_t key, uint32_t hshift, uint32
     else return (key >> hshift) & mask32;
 }
 
+// A lane's rank among the set lanes of a 64-bit lane mask (a ballot, or a per-lane mask of peers): the number of set bits
+// below the lane. v_mbcnt_lo + v_mbcnt_hi -- two instructions, the mask may stay in scalar registers -- instead of two
+// ANDs with a "lanes below me" mask and two popcounts.
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long m)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+#else
+    (void)m; return 0u;         // host pass of hipcc: parsed, never called
+#endif
+}
+
 // Optional shard-membership check riding on build and probe (hj_set_shard_check): a tuple is "foreign" when its
 // destination digit ((key - bias) >> shift) & mask differs from id. mask = 0 (and id = 0) switches it off at no
 // cost in branches: every tuple's digit is then 0.

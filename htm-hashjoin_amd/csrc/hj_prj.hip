@@ -161,16 +161,27 @@ k_radix_hist(const void* __restrict__ in, PassParams p, uint32_t* __restrict__ h
         };
         const uint32_t vEnd = (uint32_t)(((uint64_t)r.end + EPV - 1) / EPV);
         // whole wavefronts iterate together (ballots need every lane): round the trip count up
-        for (uint32_t v0 = r.begin / EPV; v0 < vEnd; v0 += kBlock) {
-            const uint32_t v = v0 + threadIdx.x;
-            live = v < vEnd;
-            const uint4 t = in4[live ? v : vEnd - 1];
-            const uint32_t i = v * EPV;
-            if constexpr (IN32) {
-                tally(t.x, i); tally(t.y, i + 1); tally(t.z, i + 2); tally(t.w, i + 3);
-            } else {
-                tally((p.zeroBad && t.y) ? 0u : t.x, i);
-                tally((p.zeroBad && t.w) ? 0u : t.z, i + 1);
+        // four 16-byte loads in flight per lane before the first ballot (one load per trip left the kernel at 4.0 TB/s:
+        // a wavefront had 1 KiB outstanding)
+        constexpr int U = 4;
+        for (uint32_t v0 = r.begin / EPV; v0 < vEnd; v0 += U * kBlock) {
+            uint4 t[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t v = v0 + (uint32_t)u * kBlock + threadIdx.x;
+                t[u] = in4[v < vEnd ? v : vEnd - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t v = v0 + (uint32_t)u * kBlock + threadIdx.x;
+                live = v < vEnd;
+                const uint32_t i = v * EPV;
+                if constexpr (IN32) {
+                    tally(t[u].x, i); tally(t[u].y, i + 1); tally(t[u].z, i + 2); tally(t[u].w, i + 3);
+                } else {
+                    tally((p.zeroBad && t[u].y) ? 0u : t[u].x, i);
+                    tally((p.zeroBad && t[u].w) ? 0u : t[u].z, i + 1);
+                }
             }
         }
         if ((threadIdx.x & 63) == 0) {
@@ -1208,7 +1219,7 @@ k_shard_scatter_stable(const uint64_t* __restrict__ in, uint32_t* __restrict__ o
     const ChunkRange r = chunk_range(p, c);
     const uint32_t fmask = p.fan - 1;
     const uint32_t len = r.end - r.begin;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t wave = threadIdx.x >> 6;
     int bits = 0;
     while ((1u << bits) < p.fan) ++bits;
     if (threadIdx.x < p.fan) cursor[threadIdx.x] = scanned[hist_index(p, r, threadIdx.x)];
@@ -1241,7 +1252,7 @@ k_shard_scatter_stable(const uint64_t* __restrict__ in, uint32_t* __restrict__ o
                 const unsigned long long m = __ballot(bit);
                 peers &= bit ? m : ~m;
             }
-            const uint32_t rk = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+            const uint32_t rk = lane_rank(peers);
             rk4[k / 4] |= rk << (8 * (k % 4));
             if (ok && rk == 0) cnt[(bin * kStabPer + k) * (kStabThreads / 64) + wave] = (uint32_t)__popcll(peers);
         }
@@ -1324,8 +1335,9 @@ k_shard_scatter_wave(const uint64_t* __restrict__ in, uint32_t* __restrict__ out
         for (int k = 0; k < kSwPer; ++k) {
             const uint64_t t = nxt[k];
             key[k] = (t >> 32) ? 0u : (uint32_t)t;                 // payload bits set: travels as key 0 (PassParams::zeroBad)
-            bin[k] = ((key[k] - p.bias) >> p.shift) & fmask;
-            okMask |= (tb + 64u * k + lane < len) ? (1u << k) : 0u;
+            const bool ok = tb + 64u * k + lane < len;
+            bin[k] = ok ? ((key[k] - p.bias) >> p.shift) & fmask : 0xFFFFFFFFu;   // past the chunk's end: no destination's
+            okMask |= ok ? (1u << k) : 0u;
             pos[k] = 0;
         }
 #pragma unroll
@@ -1337,9 +1349,9 @@ k_shard_scatter_wave(const uint64_t* __restrict__ in, uint32_t* __restrict__ out
                 uint32_t cnt = 0;
 #pragma unroll
                 for (int k = 0; k < kSwPer; ++k) {
-                    const bool mine = ((okMask >> k) & 1u) && bin[k] == (uint32_t)b;
+                    const bool mine = bin[k] == (uint32_t)b;
                     const unsigned long long m = __ballot(mine);
-                    pos[k] = mine ? off + cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)) : pos[k];
+                    pos[k] = mine ? off + cnt + lane_rank(m) : pos[k];
                     cnt += (uint32_t)__popcll(m);
                 }
                 if (lane == 0) delta[wave][b] = cur[b] - off;      // output index of staged position q = delta[bin] + q
