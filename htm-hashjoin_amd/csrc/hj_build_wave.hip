@@ -59,6 +59,9 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 #ifndef HJ_WV_WAVES_PER_CU
 #define HJ_WV_WAVES_PER_CU 16                       // chunks = resident wavefronts: one round of workgroups, no tail
 #endif
+#ifndef HJ_WV_HICMP
+#define HJ_WV_HICMP 1                               // 1: slot values are compared by their index words (32-bit compares, half the look's LDS bytes)
+#endif
 #ifndef HJ_WV_ALLIN
 #define HJ_WV_ALLIN 1                               // 1: tiles wholly inside ring and range skip the per-tuple ring test
 #endif
@@ -275,9 +278,18 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
         // together); slot values only decrease, so a slot seen below `mine` stays below it
         const bool inGran = (pos & (kGranSlots - 1)) <= kGranSlots - 4;
         const uint32_t rd = (work & inGran) ? pos : (winLoG << kGranShift);
+#if HJ_WV_HICMP
+        // slot values are (index << 32 | key) with one index per tuple, the empty pattern has the highest index word: order
+        // and equality of two values are those of their INDEX words. The look reads those alone (half the LDS bytes,
+        // two ds_read2_b32) and every compare is a 32-bit one.
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(&win[rd & (kWvWin - 1)]) + 1;
+        const uint32_t myIdx = mhi;
+        const bool c0 = w[0] < myIdx, c1 = c0 & (w[2] < myIdx), c2 = c1 & (w[4] < myIdx), c3 = c2 & (w[6] < myIdx);
+#else
         const uint64_t* w = &win[rd & (kWvWin - 1)];
         const uint64_t v0 = w[0], v1 = w[1], v2 = w[2], v3 = w[3];
         const bool c0 = v0 < mine, c1 = c0 & (v1 < mine), c2 = c1 & (v2 < mine), c3 = c2 & (v3 < mine);
+#endif
         uint32_t skip = (uint32_t)c0 + (uint32_t)c1 + (uint32_t)c2 + (uint32_t)c3;
         skip = (work & inGran) ? (skip < budget ? skip : budget) : 0u;
         pos = (pos + skip) & mask32; budget -= skip;
@@ -287,8 +299,14 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
         unsigned long long old = kEmpty;
         if (doAtomic)
             old = atomicMin(reinterpret_cast<unsigned long long*>(&win[pos & (kWvWin - 1)]), (unsigned long long)mine);
+#if HJ_WV_HICMP
+        const uint32_t oldIdx = (uint32_t)(old >> 32);
+        const bool fail = doAtomic & (oldIdx != 0xFFFFFFFFu) & (oldIdx != myIdx);
+        const bool disp = fail & (oldIdx > myIdx);                         // displaced a later tuple: carry it on
+#else
         const bool fail = doAtomic & (old != kEmpty) & (old != mine);
         const bool disp = fail & (old > mine);                             // displaced a later tuple: carry it on
+#endif
         mlo = disp ? (uint32_t)old : mlo; mhi = disp ? (uint32_t)(old >> 32) : mhi;
         const bool dropped = drop0 | drop1;
         drops += dropped ? 1u : 0u; dropSum += dropped ? (unsigned long long)key : 0ull;
@@ -457,9 +475,15 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
             while (qCount >= kWvRoundAt) retry_round();                // dense rounds; leaves room for one full step
             const bool lv = live[j], ow = own[j];
             uint32_t mlo = klo[j], mhi = idx0 + tb + lane + 64 * j;
+#if HJ_WV_HICMP
+            const uint32_t oldIdx = (uint32_t)(oldv[j] >> 32);
+            const bool fail = ow & (oldIdx != 0xFFFFFFFFu);            // the slot was taken
+            const bool disp = fail & (oldIdx > mhi);                   // ... by a later tuple: it moves on instead
+#else
             const uint64_t mine = wv_pack(mhi, mlo);
             const bool fail = ow & (oldv[j] != kEmpty);                // the slot was taken
             const bool disp = fail & (oldv[j] > mine);                 // ... by a later tuple: it moves on instead
+#endif
             mlo = disp ? (uint32_t)oldv[j] : mlo; mhi = disp ? (uint32_t)(oldv[j] >> 32) : mhi;
             const uint32_t pos = fail ? ((home[j] + 1) & mask32) : home[j];
             const bool again = fail | (lv & !ow);                      // outside ring or range: the retry round defers it
