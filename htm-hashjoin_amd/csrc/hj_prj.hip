@@ -248,17 +248,39 @@ k_scan_blocks(uint32_t* __restrict__ data, uint64_t n, uint32_t* __restrict__ bl
     if (gate_closed(gate)) return;
     const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanPerThread;
     uint32_t v[kScanPerThread], local = 0;
+    // a thread's 16 values are 64 contiguous, 64-byte aligned bytes: four 16-byte loads / stores when they all exist
+    // (one dword per instruction made every wave-instruction touch 64 different lines: 0.79 ms for the 2^26 bucket
+    // counts of the bucketised table at 2^27)
+    const bool whole = base + kScanPerThread <= n;                   // (hipMalloc'ed arrays: data is 256-byte aligned)
+    if (whole) {
+        const uint4* p4 = reinterpret_cast<const uint4*>(data + base);
 #pragma unroll
-    for (int k = 0; k < kScanPerThread; ++k) {
-        v[k] = (base + k < n) ? data[base + k] : 0;
-        local += v[k];
+        for (int q = 0; q < kScanPerThread / 4; ++q) {
+            const uint4 t = p4[q];
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kScanPerThread; ++k) v[k] = (base + k < n) ? data[base + k] : 0;
     }
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; ++k) local += v[k];
     uint32_t total;
     uint32_t ex = block_exclusive_scan(local, wsum, total);
+    if (whole) {
+        uint4* p4 = reinterpret_cast<uint4*>(data + base);
 #pragma unroll
-    for (int k = 0; k < kScanPerThread; ++k) {
-        if (base + k < n) data[base + k] = ex;
-        ex += v[k];
+        for (int q = 0; q < kScanPerThread / 4; ++q) {
+            uint4 t;
+            t.x = ex; ex += v[4 * q]; t.y = ex; ex += v[4 * q + 1]; t.z = ex; ex += v[4 * q + 2]; t.w = ex; ex += v[4 * q + 3];
+            p4[q] = t;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kScanPerThread; ++k) {
+            if (base + k < n) data[base + k] = ex;
+            ex += v[k];
+        }
     }
     if (threadIdx.x == 0) blockSums[blockIdx.x] = total;
 }
@@ -285,6 +307,16 @@ k_scan_add(uint32_t* __restrict__ data, uint64_t n, const uint32_t* __restrict__
     if (gate_closed(gate)) return;
     const uint32_t add = blockSums[blockIdx.x];
     const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanPerThread;
+    if (base + kScanPerThread <= n) {
+        uint4* p4 = reinterpret_cast<uint4*>(data + base);
+#pragma unroll
+        for (int q = 0; q < kScanPerThread / 4; ++q) {
+            uint4 t = p4[q];
+            t.x += add; t.y += add; t.z += add; t.w += add;
+            p4[q] = t;
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < kScanPerThread; ++k)
         if (base + k < n) data[base + k] += add;
