@@ -57,7 +57,13 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 #define HJ_WV_WPE 4                                 // wavefronts per SIMD the registers must allow (16 per CU: what the rings' LDS allows)
 #endif
 #ifndef HJ_WV_WAVES_PER_CU
-#define HJ_WV_WAVES_PER_CU 16                       // chunks = resident wavefronts: one round of workgroups, no tail
+#define HJ_WV_WAVES_PER_CU 16                       // resident wavefronts per CU (what the rings' LDS allows)
+#endif
+#ifndef HJ_WV_MAX_ROUNDS
+#define HJ_WV_MAX_ROUNDS 8                          // chunks = resident wavefronts x rounds (wave_chunk_len below)
+#endif
+#ifndef HJ_WV_MIN_CHUNK
+#define HJ_WV_MIN_CHUNK 65536                       // tuples: a second round of workgroups only while chunks stay this long
 #endif
 #ifndef HJ_WV_HICMP
 #define HJ_WV_HICMP 1                               // 1: slot values are compared by their index words (32-bit compares, half the look's LDS bytes)
@@ -657,13 +663,23 @@ k_wave_fill_edges(uint64_t* __restrict__ table, const Counters* __restrict__ ctr
 // ---- host side ----------------------------------------------------------------------------------------------------
 size_t wave_lds_bytes() { return kWvLdsBytes; }
 bool wave_supported(uint64_t tableSize) { return tableSize >= (uint64_t)kWvWin; }
-uint32_t wave_max_chunks(int nCU) { return (uint32_t)HJ_WV_WAVES_PER_CU * (uint32_t)nCU; }
+uint32_t wave_max_chunks(int nCU) { return (uint32_t)HJ_WV_WAVES_PER_CU * (uint32_t)HJ_WV_MAX_ROUNDS * (uint32_t)nCU; }
 size_t wave_bounds_bytes(int nCU) { return (5 * (size_t)wave_max_chunks(nCU) + 4) * sizeof(uint32_t); }   // raw, bounds (+1), starts (+1), dcounts, ccounts
 static uint64_t wave_chunk_len(uint64_t n, int nCU)
 {
-    // one chunk per resident wavefront: a single round of workgroups, no tail
-    const uint32_t maxChunks = wave_max_chunks(nCU);
-    uint64_t chunkLen = (n + maxChunks - 1) / maxChunks;
+    // One chunk per resident wavefront is a single round of workgroups -- and the kernel then lasts as long as its
+    // SLOWEST wavefront: the streams of 4096 wavefronts do not advance at the same rate (memory channels, neighbours on the
+    // CU), and with a static split nobody takes over from a wavefront that is done. Measured: the kernel's time is
+    // 97 us + 1.81 ms per 2^29 tuples from 2^27 to 2^30 -- a size-independent ~100 us of waiting for stragglers. So large
+    // relations are cut into several rounds' worth of chunks and the hardware's workgroup dispatcher does the balancing
+    // (a workgroup that finishes makes room for the next four chunks): 2^30 tuples in 4 x 4096 chunks 3.68 -> 3.49 ms.
+    // Chunks stay >= HJ_WV_MIN_CHUNK tuples, though: every chunk pays for its ring (fill, final flush) and for two seam
+    // tiles, and at 2^27 two rounds of 16384-tuple chunks were 2 % SLOWER than one round, four rounds 6 %.
+    const uint32_t resident = (uint32_t)HJ_WV_WAVES_PER_CU * (uint32_t)nCU;
+    uint64_t rounds = n / ((uint64_t)resident * HJ_WV_MIN_CHUNK);
+    rounds = rounds < 1 ? 1 : rounds > HJ_WV_MAX_ROUNDS ? HJ_WV_MAX_ROUNDS : rounds;
+    const uint64_t chunks = (uint64_t)resident * rounds;
+    uint64_t chunkLen = (n + chunks - 1) / chunks;
     chunkLen = (chunkLen + kWvTile - 1) / kWvTile * kWvTile;
     return chunkLen < (uint64_t)kWvTile * 4 ? (uint64_t)kWvTile * 4 : chunkLen;
 }
