@@ -63,7 +63,7 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 #define HJ_WV_MAX_ROUNDS 8                          // chunks = resident wavefronts x rounds (wave_chunk_len below)
 #endif
 #ifndef HJ_WV_MIN_CHUNK
-#define HJ_WV_MIN_CHUNK 65536                       // tuples: a second round of workgroups only while chunks stay this long
+#define HJ_WV_MIN_CHUNK 32768                       // tuples: a second round of workgroups only while chunks stay this long
 #endif
 #ifndef HJ_WV_HICMP
 #define HJ_WV_HICMP 1                               // 1: slot values are compared by their index words (32-bit compares, half the look's LDS bytes)
@@ -672,9 +672,11 @@ static uint64_t wave_chunk_len(uint64_t n, int nCU)
     // CU), and with a static split nobody takes over from a wavefront that is done. Measured: the kernel's time is
     // 97 us + 1.81 ms per 2^29 tuples from 2^27 to 2^30 -- a size-independent ~100 us of waiting for stragglers. So large
     // relations are cut into several rounds' worth of chunks and the hardware's workgroup dispatcher does the balancing
-    // (a workgroup that finishes makes room for the next four chunks): 2^30 tuples in 4 x 4096 chunks 3.68 -> 3.49 ms.
+    // (a workgroup that finishes makes room for the next four chunks): 2^30 tuples in 4 x 4096 chunks 3.68 -> 3.49 ms,
+    // in 8 x 4096 chunks 3.46 ms.
     // Chunks stay >= HJ_WV_MIN_CHUNK tuples, though: every chunk pays for its ring (fill, final flush) and for two seam
-    // tiles, and at 2^27 two rounds of 16384-tuple chunks were 2 % SLOWER than one round, four rounds 6 %.
+    // tiles, and at 2^27 two rounds of 16384-tuple chunks were 2 % SLOWER than one round, four rounds 6 % (32768 against
+    // 65536 as the minimum: the same at 2^28, -2 % at 2^29, -1..3 % at 2^30; 16 rounds instead of 8: slower).
     const uint32_t resident = (uint32_t)HJ_WV_WAVES_PER_CU * (uint32_t)nCU;
     uint64_t rounds = n / ((uint64_t)resident * HJ_WV_MIN_CHUNK);
     rounds = rounds < 1 ? 1 : rounds > HJ_WV_MAX_ROUNDS ? HJ_WV_MAX_ROUNDS : rounds;
