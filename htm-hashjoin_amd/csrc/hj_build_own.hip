@@ -66,6 +66,12 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 
 __device__ __forceinline__ uint64_t pack64(uint32_t hi, uint32_t lo) { return ((uint64_t)hi << 32) | lo; }
 
+#ifndef HJ_OWN_MAX_ROUNDS
+#define HJ_OWN_MAX_ROUNDS 1                      // rounds of workgroups for large relations (see launch_build_own)
+#endif
+#ifndef HJ_OWN_MIN_CHUNK
+#define HJ_OWN_MIN_CHUNK 524288                  // tuples per chunk below which no further round is added
+#endif
 #ifndef HJ_DRAIN_INPLACE
 #define HJ_DRAIN_INPLACE 1
 #endif
@@ -628,7 +634,10 @@ hipError_t launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshi
     if ((e = hipMemsetAsync(queueCount, 0, sizeof(unsigned long long), s)) != hipSuccess) return e;
     // one chunk per resident workgroup (2 per CU: 76 KiB LDS each): a single wave of workgroups, no tail,
     // and the fewest chunk seams (measured: 512 chunks beat 768/1024/2048/4096 on MI355X)
-    const int nChunks = 2 * (nCU > 0 ? nCU : 256);
+    const int resident = 2 * (nCU > 0 ? nCU : 256);
+    uint64_t rounds = n / ((uint64_t)resident * HJ_OWN_MIN_CHUNK);
+    rounds = rounds < 1 ? 1 : rounds > HJ_OWN_MAX_ROUNDS ? HJ_OWN_MAX_ROUNDS : rounds;
+    const uint64_t nChunks = (uint64_t)resident * rounds;
     uint64_t chunkLen = (n + nChunks - 1) / nChunks;
     chunkLen = (chunkLen + kOwnTile - 1) / kOwnTile * kOwnTile;
     if (chunkLen < (uint64_t)kOwnTile * 4) chunkLen = (uint64_t)kOwnTile * 4;
