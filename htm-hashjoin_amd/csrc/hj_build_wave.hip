@@ -8,7 +8,9 @@
 // waiting (51 % of the wave-cycles parked at barriers and on dependent LDS round trips, profiles/r01_*). Here
 // nothing is shared between wavefronts, so nothing has to be waited for:
 //
-//   * R is cut into one contiguous chunk per resident wavefront (16 per CU). The chunk's slot range
+//   * R is cut into contiguous chunks, one per wavefront: as many as there are resident wavefronts (16 per CU), and
+//     for large relations up to eight times as many (wave_chunk_len: later workgroups take over from the ones that
+//     finish, which balances the wavefronts' uneven progress). The chunk's slot range
 //     [bounds[c], bounds[c+1]) is fixed BEFORE the build by a pre-pass that looks at the first 64 tuples of
 //     every chunk (k_wave_bounds): start = lowest home slot among them, made monotone by a prefix maximum.
 //     A wavefront owns its range outright -- no claims, no owner table, no atomics on HBM.
