@@ -1188,7 +1188,11 @@ hipError_t launch_prj(const PrjPlan& pl, const PrjBuffers& buf, const uint64_t* 
     if (S && (e = partition_relation(pl, w, S, nS, tmp, partS, w.offS, exact, s)) != hipSuccess) return e;
     if (evPartDone && (e = hipEventRecord(evPartDone, s)) != hipSuccess) return e;
     const uint32_t P = 1u << pl.radixBits;
-    const unsigned grid = P < (uint32_t)nCU ? P : (unsigned)nCU;   // one persistent workgroup per CU
+#ifndef HJ_JOIN_ROUNDS
+#define HJ_JOIN_ROUNDS 1
+#endif
+    const unsigned want = (unsigned)nCU * HJ_JOIN_ROUNDS;          // one persistent workgroup per CU (x rounds: development flag)
+    const unsigned grid = P < want ? P : want;
     static_assert(kJoinSlots * 2 == 65536, "two 16-bit counters per LDS word cover every 16-bit key remainder");
     const PartView none{nullptr, nullptr, nullptr, 0u, 0u, 1u};
     auto join = [&](const PartView& vr, const PartView& vs, Gate gate) {
