@@ -64,6 +64,9 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 #ifndef HJ_WV_MAX_ROUNDS
 #define HJ_WV_MAX_ROUNDS 8                          // chunks = resident wavefronts x rounds (wave_chunk_len below)
 #endif
+#ifndef HJ_WV_SKEW
+#define HJ_WV_SKEW 0                                // extra tiles per chunk: chunk starts off the power-of-two stride
+#endif
 #ifndef HJ_WV_MIN_CHUNK
 #define HJ_WV_MIN_CHUNK 32768                       // tuples: a second round of workgroups only while chunks stay this long
 #endif
@@ -684,7 +687,7 @@ static uint64_t wave_chunk_len(uint64_t n, int nCU)
     rounds = rounds < 1 ? 1 : rounds > HJ_WV_MAX_ROUNDS ? HJ_WV_MAX_ROUNDS : rounds;
     const uint64_t chunks = (uint64_t)resident * rounds;
     uint64_t chunkLen = (n + chunks - 1) / chunks;
-    chunkLen = (chunkLen + kWvTile - 1) / kWvTile * kWvTile;
+    chunkLen = (chunkLen + kWvTile - 1) / kWvTile * kWvTile + (uint64_t)kWvTile * HJ_WV_SKEW;
     return chunkLen < (uint64_t)kWvTile * 4 ? (uint64_t)kWvTile * 4 : chunkLen;
 }
 static uint64_t wave_slice_len(uint64_t chunkLen) { return chunkLen + kWvLook + kWvOverlap; }
