@@ -47,6 +47,7 @@ def test_metric_size_uniform_against_the_sequential_oracle():
     S = hj.generate_data("sorted", N)
     want = oracle.build_probe_seq(R, S, 4)
     assert want["totalMatches"] + want["conflicts"] == N
+    R32, S32 = R.astype(np.uint32), S.astype(np.uint32)
     with hj.HashJoinContext(0) as c:
         dR = c.dev_alloc(N * 8); c.copy_h2d(dR, R)
         dS = c.dev_alloc(N * 8); c.copy_h2d(dS, S)
@@ -61,6 +62,18 @@ def test_metric_size_uniform_against_the_sequential_oracle():
             for k in ("conflicts", "totalMatches", "inputSum", "tableSumHalf", "tableSumFull", "conflictSum"):
                 assert got[k] == want[k], (variant, k, got[k], want[k])
             assert got["outputSum"] == want["outputSumAtomic"]
+        # the bare-key entry points a radix shard runs after the exchange, at the same size: at 2^30 the wavefront build cuts
+        # the relation into eight rounds' worth of chunks, and the 32-bit instances of the kernels take that path too
+        c.copy_h2d(dR, R32); c.copy_h2d(dS, S32)
+        del R32, S32
+        c.reserve("atomic", N, N)
+        c.build_keys(dR, N, 0, 2 * N)
+        c.probe_keys(dS, N)
+        c.checksums()
+        got = c.fetch()
+        assert got["buildVariant"] == 3
+        for k in ("conflicts", "totalMatches", "inputSum", "tableSumFull", "conflictSum"):
+            assert got[k] == want[k], ("keys", k, got[k], want[k])
         c.dev_free(dR); c.dev_free(dS)
     # the numbers every bench line of rounds 1 and 2 printed for this workload
     assert (want["conflicts"], want["totalMatches"]) == (180852797, 892889027)
