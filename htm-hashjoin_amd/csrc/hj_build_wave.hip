@@ -64,6 +64,12 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 #ifndef HJ_WV_MAX_ROUNDS
 #define HJ_WV_MAX_ROUNDS 8                          // chunks = resident wavefronts x rounds (wave_chunk_len below)
 #endif
+#ifndef HJ_WV_PRIO
+#define HJ_WV_PRIO 2                                // 2: issue priorities rotate in time among a CU's workgroup slots (0: off, 1: static, inverse to age)
+#endif
+#ifndef HJ_WV_PRIO_SHIFT
+#define HJ_WV_PRIO_SHIFT 10                         // rotation period = 2^shift ticks of the 100 MHz clock (10.24 us)
+#endif
 #ifndef HJ_WV_SKEW
 #define HJ_WV_SKEW 0                                // extra tiles per chunk: chunk starts off the power-of-two stride
 #endif
@@ -202,6 +208,16 @@ k_wave_bounds_scan(const uint32_t* __restrict__ raw, uint32_t nChunks, uint32_t 
     if (t == 0) bounds[nChunks] = numGran;
 }
 
+#ifdef HJ_WV_CLOCKS
+// Development builds only (tools/mk_variant.sh ... "-DHJ_WV_CLOCKS", tools/wave_clocks.py): when every chunk's wavefront
+// started and ended, in ticks of the 100 MHz wall clock. Not in the product library.
+__device__ uint32_t g_wvClk[2 * 65536];
+extern "C" int hj_debug_wave_clocks(uint32_t* out, uint32_t nChunks)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wvClk), (size_t)nChunks * 2 * sizeof(uint32_t));
+}
+#endif
+
 // ---- the build ------------------------------------------------------------------------------------------------
 template <bool KEY32, bool CHECK, bool HTM>
 __global__ void __launch_bounds__(kWvThreads, HJ_WV_WPE)
@@ -216,11 +232,17 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t c = blockIdx.x * kWvWaves + wave;
     if (c >= nChunks) return;                                            // whole wavefronts leave; nobody waits for them
+#ifdef HJ_WV_CLOCKS
+    if (lane == 0 && c < 65536) g_wvClk[2 * c] = (uint32_t)wall_clock64();
+#endif
     uint64_t* const win = lds + wave * kWvWin;                           // ring: slot s lives at win[s & (kWvWin - 1)]
     uint32_t* const myQPos = reinterpret_cast<uint32_t*>(lds + kWvWaves * kWvWin) + wave * 3 * kWvQCap;
     uint32_t* const myQLo = myQPos + kWvQCap;
     uint32_t* const myQHi = myQLo + kWvQCap;
 
+#if HJ_WV_PRIO
+    const uint32_t prioDiv = (gridDim.x + 3u) / 4u > 0 ? ((gridDim.x <= 1024u ? gridDim.x : 1024u) + 3u) / 4u : 1u;   // workgroups per dispatch round of the first four
+#endif
     const uint64_t cb = starts[c];
     const uint32_t clen = starts[c + 1] - starts[c];                     // the chunk proper: its tuples are counted here
     // ... and kWvOverlap positions of the next chunk are read too: its stragglers below the seam are inserted here
@@ -401,6 +423,30 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
             klo[j] = (uint32_t)nxt[p][j];
             khi[j] = KEY32 ? 0u : (uint32_t)((uint64_t)nxt[p][j] >> 32);
         }
+#if HJ_WV_PRIO
+        {   // The CU arbitrates oldest wavefront first, and the four workgroups of a CU are dispatched one after the other:
+            // measured at 2^27 (tools/wave_clocks.py, every wavefront's start and end), the wavefronts of a CU's first
+            // workgroup took 349 us for their chunk, those of the second 380, the third 421, the fourth 470 -- the kernel
+            // lasted 497 us and ran half empty for its last fifth. So every wavefront sets its issue priority per tile
+            // from the wall clock: the four workgroup slots of a CU take turns at the top (10 us each). With it: 389 / 398 /
+            // 398 / 400 us, kernel 446 us. (From 2^28 tuples on the later rounds of workgroups do the balancing; no gain or
+            // loss there. An input without retry rounds is memory bound and hardly reacts: the arbitration that is
+            // unfair to its younger wavefronts is the memory system's.)
+            const uint32_t slot = (blockIdx.x / prioDiv) & 3u;
+#if HJ_WV_PRIO == 1
+            const uint32_t pr = slot;
+            if (tb == 0) {
+#else
+            const uint32_t pr = ((uint32_t)(wall_clock64() >> HJ_WV_PRIO_SHIFT) + slot) & 3u;
+            {
+#endif
+                if (pr == 0) __builtin_amdgcn_s_setprio(0);
+                else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+                else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+                else __builtin_amdgcn_s_setprio(3);
+            }
+        }
+#endif
         const bool full = (tb + kWvTile <= clen) & (tb >= kWvOverlap);   // wave-uniform: no head zone, no overlap zone
         issue(nxt[p], tb + kWvPf * kWvTile);
         const uint32_t roundsAtTileStart = rounds;
@@ -529,6 +575,9 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
         if constexpr (HTM) ccounts[c] = cCount;
     }
 
+#ifdef HJ_WV_CLOCKS
+    if (lane == 0 && c < 65536) g_wvClk[2 * c + 1] = (uint32_t)wall_clock64();
+#endif
     // counters: one atomic per wavefront
     unsigned long long c0 = drops, c3 = bad | ((unsigned long long)foreign << 32);
     const unsigned long long c4 = dCount;
