@@ -66,6 +66,12 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 
 __device__ __forceinline__ uint64_t pack64(uint32_t hi, uint32_t lo) { return ((uint64_t)hi << 32) | lo; }
 
+#ifndef HJ_OWN_PRIO
+#define HJ_OWN_PRIO 0
+#endif
+#ifndef HJ_OWN_PRIO_SHIFT
+#define HJ_OWN_PRIO_SHIFT 10
+#endif
 #ifndef HJ_OWN_MAX_ROUNDS
 #define HJ_OWN_MAX_ROUNDS 1                      // rounds of workgroups for large relations (see launch_build_own)
 #endif
@@ -237,6 +243,14 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
         uint32_t klo[kPerThread], khi[kPerThread];
 #pragma unroll
         for (int j = 0; j < kPerThread; ++j) { klo[j] = (uint32_t)nxt[j]; khi[j] = (uint32_t)(nxt[j] >> 32); }
+#if HJ_OWN_PRIO
+        {   // the CU's two workgroup slots take turns at the higher issue priority (hj_build_wave.hip: oldest-first
+            // arbitration lets the workgroup a CU received first finish well before the second)
+            const uint32_t slot = (blockIdx.x / ((gridDim.x + 1u) / 2u)) & 1u;
+            if ((((uint32_t)(wall_clock64() >> HJ_OWN_PRIO_SHIFT)) + slot) & 1u) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
         const bool full = tb + kOwnTile <= clen;                      // wave-uniform
         const bool firstTile = tb == 0, lastTile = tb + kOwnTile >= clen;
         if (!lastTile) {
