@@ -37,7 +37,10 @@
 
 namespace hj {
 
-constexpr int kWvThreads = 256;                     // 4 wavefronts per workgroup; they never synchronise
+#ifndef HJ_WV_THREADS
+#define HJ_WV_THREADS 256
+#endif
+constexpr int kWvThreads = HJ_WV_THREADS;           // 4 wavefronts per workgroup; they never synchronise
 constexpr int kWvWaves = kWvThreads / 64;
 constexpr uint32_t kGranShift = kWvGranShift;       // retire granule: 128 slots = 1 KiB = 64 lanes x 16 bytes
 constexpr uint32_t kGranSlots = 1u << kGranShift;
@@ -241,7 +244,9 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
     uint32_t* const myQHi = myQLo + kWvQCap;
 
 #if HJ_WV_PRIO
-    const uint32_t prioDiv = (gridDim.x + 3u) / 4u > 0 ? ((gridDim.x <= 1024u ? gridDim.x : 1024u) + 3u) / 4u : 1u;   // workgroups per dispatch round of the first four
+    // workgroups per quarter of the first, resident round (a 256-CU device assumed: only the fairness of the rotation depends on it)
+    constexpr uint32_t kResidentWG = (uint32_t)HJ_WV_WAVES_PER_CU * 256u / (uint32_t)kWvWaves;
+    const uint32_t prioDiv = ((gridDim.x <= kResidentWG ? gridDim.x : kResidentWG) + 3u) / 4u;
 #endif
     const uint64_t cb = starts[c];
     const uint32_t clen = starts[c + 1] - starts[c];                     // the chunk proper: its tuples are counted here
