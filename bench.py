@@ -3,6 +3,12 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--log2n 30] [--dist uniform]
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process starts N fresh rank processes of itself
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one per GPU) BEFORE it touches the GPU in any way, waits for them and
+relays rank 0's JSON line; it exits non-zero if a rank fails or fewer than N devices are visible. Under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (the driver's N > 1 command) the ranks are
+already there and each process is one of them; `--gpus` that disagrees with WORLD_SIZE is an error, never a silent N=1.
+
 One "step" = one pass of the hot path over one batch: build(R) -> probe(S) (the build writes
 every reachable table slot once, empties included: there is no separate clear) with R and S
 already resident in HBM (DataGen inputs, generated on the host and copied
@@ -32,7 +38,9 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak, MI355X_MICROARCH.md "Chip-lev
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="GPUs (= ranks) of this node; default: WORLD_SIZE if a launcher set it, else 1. N > 1 without "
+                         "WORLD_SIZE: bench.py starts the N ranks itself")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2n", type=int, default=30, help="per-GPU |R| = |S| = 2^log2n")
@@ -50,10 +58,18 @@ def parse():
                     help="N>1: destination = low key bits (default: BASELINE config 4's all-to-all, (G-1)/G of the tuples "
                          "cross xGMI), high key bits (range split), or auto = high when >= 3/4 of every rank's tuples stay "
                          "put under it (sharded.py)")
-    ap.add_argument("--exchange", default="p2p", choices=["p2p", "a2a"],
+    ap.add_argument("--exchange", default="auto", choices=["auto", "p2p", "a2a"],
                     help="N>1: batch of pairwise isend/irecv per relation, or one all_to_all_single per relation "
-                         "(falls back to p2p for a step whose largest per-peer message is >= 512 MiB)")
-    return ap.parse_args()
+                         "(falls back to p2p for a step whose largest per-peer message is >= 512 MiB); auto = whichever "
+                         "form the pre-flight exchange (sharded.exchange_selfcheck: both forms at 1 MiB per peer and at "
+                         "the step's own size, every element checked) delivered correctly and faster")
+    a = ap.parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if a.gpus is None:
+        a.gpus = int(env_world) if env_world else 1
+    if a.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    return a
 
 
 def to_device(np_u64, torch, dev):
@@ -243,15 +259,89 @@ def cpu_baseline_prj(log2n):
                       f"pk/fk generator, best of 2: {us / 1e3:.1f} ms; compare other_workloads.prj_local_shuffle_1024"}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n_ranks, argv):
+    """--gpus N without a launcher: start N fresh children of this very script, one rank per GPU, and relay rank 0's
+    JSON line. The parent has made no HIP call and never will (torch.cuda.device_count() reads the device list without
+    initialising the runtime on this image); every child is a new process that initialises its own GPU -- no exec of a
+    process that has touched the device. Returns the exit code."""
+    import subprocess
+    stub = os.environ.get("HJ_BENCH_TEST_ENGINE")
+    if not stub:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n_ranks:
+            print(f"bench.py --gpus {n_ranks}: only {have} HIP device(s) visible (there is no CPU fallback)", file=sys.stderr)
+            return 3
+    port = _free_port()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HJ_BENCH_LAUNCHER="self-spawned")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this pool
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    # rank 0's stdout is the one JSON line; read it while waiting so a large line cannot fill the pipe
+    import threading
+    out = []
+    reader = threading.Thread(target=lambda: out.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    alive = set(range(n_ranks))
+    while alive:
+        for r in list(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py --gpus {n_ranks}: rank {r} exited with {code}; stopping the others", file=sys.stderr)
+                for o in alive:
+                    procs[o].terminate()                         # exactly the PIDs started above
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    text = (out[0] if out else "") or ""
+    lines = [ln for ln in text.splitlines() if ln.strip().startswith("{")]
+    if rc == 0 and not lines:
+        print(f"bench.py --gpus {n_ranks}: rank 0 printed no JSON line", file=sys.stderr)
+        rc = 4
+    if rc == 0:
+        print(lines[-1], flush=True)
+    return rc
+
+
 def main():
     a = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and a.gpus > 1:
+        raise SystemExit(launch_ranks(a.gpus, sys.argv[1:]))      # before anything touches the GPU
+    if env_world is not None and int(env_world) != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} disagrees with WORLD_SIZE={env_world} (refusing to report a "
+                         f"{a.gpus}-GPU line from {env_world} rank(s))")
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # TEST HOOK (tests/test_bench_launcher.py): "module:Class" of a stand-in compute engine. With it the ranks talk gloo
+    # on the CPU, so the launcher, the rendezvous, the pre-flight exchange and the JSON contract can be driven where
+    # there is no GPU. The product engine is the only one this file knows; nothing is ever measured with the stand-in
+    # (the line says "engine": "TEST STAND-IN ...").
+    stub = os.environ.get("HJ_BENCH_TEST_ENGINE") if world > 1 else None
+    if stub is None:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f"bench.py: rank {rank} needs HIP device {local_rank}, {torch.cuda.device_count()} visible")
+        torch.cuda.set_device(local_rank)
     import htm_hashjoin_amd as hj
 
     n = 1 << a.log2n
@@ -260,14 +350,24 @@ def main():
         from htm_hashjoin_amd import sharded
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        engine = device = None
+        if stub is not None:
+            import importlib
+            mod, cls = stub.split(":")
+            engine, device = getattr(importlib.import_module(mod), cls)(), "cpu"
         # RCCL prints a version banner on STDOUT when the first communicator comes up; the contract is one JSON
         # line there, so fd 1 points at stderr until the line is ready
         sys.stdout.flush()
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist_mod.init_process_group("nccl", rank=rank, world_size=world)
-            line = sharded.bench_sharded(a, torch, dist_mod, hj, rank, world, local_rank)
+            dist_mod.init_process_group("gloo" if stub is not None else "nccl", rank=rank, world_size=world)
+            line = sharded.bench_sharded(a, torch, dist_mod, hj, rank, world, local_rank, engine=engine, device=device)
+            line["rccl_world"] = dist_mod.get_world_size()
+            line["backend"] = dist_mod.get_backend()
+            line["launcher"] = os.environ.get("HJ_BENCH_LAUNCHER", "external (torch.distributed.run)" if world > 1 else "none")
+            if stub is not None:
+                line["engine"] = f"TEST STAND-IN {stub} over gloo: not a measurement"
         finally:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
@@ -340,7 +440,7 @@ def main():
 
     line = {
         "metric": "Mtuples/sec build+probe, |R|=|S|=1B uint32, uniform vs local_shuffle",
-        "value": main_leg["mtuples_per_s"], "unit": "Mtuples/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+        "value": main_leg["mtuples_per_s"], "unit": "Mtuples/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": main_leg["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64 tuples (u32 key), integer", "data": "synthetic (DataGen restatement, srand(0) glibc stream)",
         "config": {"workload": f"open-addressing build+probe (atomic), |R|=|S|=2^{a.log2n}, dataDistr={a.dist} "

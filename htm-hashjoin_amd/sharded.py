@@ -413,6 +413,73 @@ def squeeze_into_range(v, n, lo, width, np):
     return v + np.uint64(lo + 1)
 
 
+def exchange_selfcheck(job, n_step_keys):
+    """Pre-flight of the exchange, before anything is timed: both forms (`all_to_all_single`, the pairwise batch) move a
+    known pattern at 1 MiB per peer and at the step's own per-peer size through ShardedJoin._exchange_async -- the very
+    function the steps use -- and EVERY received element is compared with what its sender must have put there. The first
+    multi-rank contact of this code with RCCL happens here, where a wrong byte costs a line in the report, not a wrong
+    benchmark (all_to_all_single of this RCCL build dropped half of a >= 2 GiB per-peer message at world 1,
+    tools/dbg/a2a_check.py). Returns {size: {form: {"ok", "ms"}}}, identical on every rank (flags MIN-reduced, times
+    MAX-reduced). A form is skipped at a size where a per-peer message would exceed ShardedJoin.max_msg_tuples for
+    all_to_all_single (the step falls back to the batch there anyway)."""
+    torch, dist, world, rank, e = job.torch, job.dist, job.world, job.rank, job.e
+    report = {}
+    saved = job.exchange, job._step_max_msg, job.last_exchange_form
+    sizes = []
+    for name, per_peer in (("1MiB_per_peer", 1 << 18), ("step_size", int(n_step_keys))):
+        if per_peer > 0 and all(per_peer != s for _, s in sizes):
+            sizes.append((name, per_peer))
+    for name, per_peer in sizes:
+        report[name] = {"keys_per_peer": per_peer}
+        for form in ("a2a", "p2p"):
+            if form == "a2a" and per_peer > job.max_msg_tuples:
+                report[name][form] = {"ok": None, "ms": None, "skipped": "per-peer message above max_msg_tuples: the step uses the batch"}
+                continue
+            send = e.empty_keys(per_peer * world)
+            # element i of the piece rank s sends to rank d: (s * world + d) * 40503 + i, wrapped to 31 bits
+            i = torch.arange(per_peer, dtype=torch.int64, device=send.device)
+            for d in range(world):
+                send[d * per_peer:(d + 1) * per_peer] = (((rank * world + d) * 40503 + i) & 0x7FFFFFFF).to(torch.int32)
+            counts = [per_peer] * world
+            job.exchange, job._step_max_msg = form, per_peer
+            ok, best = 1, None
+            for _ in range(2):                                   # the second pass is the timed one (first: connections come up)
+                e.sync()
+                dist.barrier()
+                t0 = time.perf_counter()
+                got, works = job._exchange_async(send, counts, counts)
+                for w in works:
+                    w.wait()
+                e.sync()
+                best = (time.perf_counter() - t0) * 1e3
+                for s_ in range(world):
+                    want = (((s_ * world + rank) * 40503 + i) & 0x7FFFFFFF).to(torch.int32)
+                    if not torch.equal(got[s_ * per_peer:(s_ + 1) * per_peer], want):
+                        ok = 0
+                del got
+            used = job.last_exchange_form
+            ok = job._all_reduce_scalar(ok, "MIN")
+            ms = job._all_reduce_scalar(int(best * 1e6), "MAX") / 1e6
+            report[name][form] = {"ok": bool(ok), "ms": ms, "form": used,
+                                  "GBps_out_per_rank": 4.0 * per_peer * (world - 1) / (ms * 1e-3) / 1e9 if ms else None}
+            del send
+    job.exchange, job._step_max_msg, job.last_exchange_form = saved
+    return report
+
+
+def pick_exchange(report):
+    """"a2a" if all_to_all_single delivered every element at every size it was tried and was not slower than the batch
+    at the step's size, else "p2p"; a report in which the batch itself failed raises (nothing to fall back to)."""
+    for size in report.values():
+        if size["p2p"]["ok"] is False:
+            raise RuntimeError(f"exchange self-check: the pairwise batch delivered wrong data: {report}")
+    a2a_ok = all(size["a2a"]["ok"] is True for size in report.values())
+    last = list(report.values())[-1]
+    if a2a_ok and last["a2a"]["ms"] <= last["p2p"]["ms"]:
+        return "a2a"
+    return "p2p"
+
+
 def bench_sharded(args, torch, dist, hj, rank, world, local_rank, engine=None, device=None):
     """bench.py's N > 1 leg = BASELINE config 4: radix join across the GPUs of one node with an all-to-all partition
     exchange. Default = WEAK scaling: every rank holds 2^log2n tuples of R and of S (the N=1 workload per GPU; 8 GPUs x
@@ -454,7 +521,20 @@ def bench_sharded(args, torch, dist, hj, rank, world, local_rank, engine=None, d
     eng = engine if engine is not None else HipShardEngine(hj, torch, local_rank, build_variant=args.build_variant)
     table_size = 2 * n
     total_keys = min(world * n, wrap)                                # the keys lie in [1, relation size] (or the whole key space)
-    exchange = getattr(args, "exchange", "p2p")
+    exchange = getattr(args, "exchange", "auto")
+    # pre-flight: the first thing the ranks do together is an exchange whose every element is checked
+    selfcheck = None
+    if world > 1:
+        probe_job = ShardedJoin(eng, torch, dist, rank, world, split="low", max_key=total_keys, exchange="p2p")
+        selfcheck = exchange_selfcheck(probe_job, (n + world - 1) // world)
+        if exchange == "auto":
+            exchange = pick_exchange(selfcheck)
+        elif exchange == "a2a" and not all(sz["a2a"]["ok"] is not False for sz in selfcheck.values()):
+            raise RuntimeError(f"--exchange a2a: all_to_all_single failed the self-check: {selfcheck}")
+        else:
+            pick_exchange(selfcheck)                                 # raises if even the batch is wrong
+    elif exchange == "auto":
+        exchange = "p2p"
 
     def new_job(split):
         return ShardedJoin(eng, torch, dist, rank, world, split=split,
@@ -517,6 +597,7 @@ def bench_sharded(args, torch, dist, hj, rank, world, local_rank, engine=None, d
         "checks": {"matches_plus_conflicts_eq_rSize": (res["totalMatches"] + res["conflicts"] == n * world) if unique_domain else None,
                    "unique_keys_all_match": (res["totalMatches"] == n * world) if unique else None,
                    "tableSum_plus_conflictSum_eq_inputSum": res["tableSumFull"] + res["conflictSum"] == res["inputSum"]},
+        "a2a_selfcheck": selfcheck, "exchange_chosen": exchange,
         "exchange": {**res["exchange"], "form": job.last_exchange_form,
                      "bytes_sent_per_rank_per_step": 4 * (res["exchange"]["sent_r"] + res["exchange"]["sent_s"])},
         "phase_ms": phase_ms,
