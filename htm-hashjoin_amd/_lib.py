@@ -9,6 +9,15 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhtmjoin_hip.so")
+# Development tools (tools/run_variants.sh and friends) time A/B builds of the library made by tools/mk_variant.sh: they
+# name the variant here instead of copying it over the product library (round-2 ADVICE: an interrupted script left a
+# variant in place). Nothing but those tools sets it; the path is printed so that a measurement can never pass a
+# variant off as the product.
+_DEV = os.environ.get("HJ_DEV_LIB_VARIANT")
+if _DEV:
+    LIB_PATH = os.path.abspath(_DEV)
+    import sys as _sys
+    print(f"[htm_hashjoin_amd] DEVELOPMENT VARIANT LIBRARY: {LIB_PATH}", file=_sys.stderr)
 
 HJ_OK = 0
 HJ_ERR_INVALID = -1

@@ -285,12 +285,22 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
         while (winLoG < target) {
             ulonglong2* src = reinterpret_cast<ulonglong2*>(win + ((winLoG & (kWvGran - 1)) << kGranShift)) + lane;
             const ulonglong2 t = *src;
+#if defined(HJ_WV_ABL_NOSTORE)
+            if (t.x == 0x1234567ull) table[lane] = t.y;        // ablation (development builds): the retire stores never happen
+#elif defined(HJ_WV_ABL_HALFSTORE)
+            {   // ablation: 4 bytes per slot leave (the key words), 512 B per granule
+                typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+                u2 vv; vv.x = (uint32_t)t.x; vv.y = (uint32_t)t.y;
+                __builtin_nontemporal_store(vv, reinterpret_cast<u2*>(reinterpret_cast<uint32_t*>(table) + ((uint64_t)winLoG << kGranShift)) + lane);
+            }
+#else
             {   // written once and not read again by this kernel: nontemporal stores (-1.5 % kernel time at 2^30, and
                 // the probe that follows runs 1 % faster; nontemporal LOADS of R were slower)
                 typedef unsigned long long v2 __attribute__((ext_vector_type(2)));
                 v2 vv; vv.x = t.x; vv.y = t.y;
                 __builtin_nontemporal_store(vv, reinterpret_cast<v2*>(table + ((uint64_t)winLoG << kGranShift)) + lane);
             }
+#endif
             *src = make_ulonglong2(kEmpty, kEmpty);
             ++winLoG;
         }

@@ -548,7 +548,12 @@ k_radix_scatter_frag(const void* __restrict__ in, uint32_t* __restrict__ out, Fr
     __shared__ uint32_t prefix[IN32 ? kMaxInFrags + 1 : 1];   // pass 2: keys of this chunk before input fragment i
     __shared__ uint32_t wsum[NT / 64];
 
-    if (*reinterpret_cast<volatile unsigned long long*>(&ctr->prjFallback)) return;
+    // The fallback word is set by OTHER workgroups of this very launch (below): every wavefront reading it for itself
+    // could split a workgroup -- some wavefronts gone, the rest scanning with stale wsum[] entries, and pass 2 would then
+    // read through garbage prefixes. One thread reads, the workgroup decides together (round-2 ADVICE).
+    if (threadIdx.x == 0) sAbort = *reinterpret_cast<volatile unsigned long long*>(&ctr->prjFallback) != 0;
+    __syncthreads();
+    if (sAbort) return;
     const uint32_t c = blockIdx.x;
     const uint32_t seg = c / p.C, local = c - seg * p.C;
     const uint32_t fmask = p.fan - 1;
@@ -577,6 +582,11 @@ k_radix_scatter_frag(const void* __restrict__ in, uint32_t* __restrict__ out, Fr
         }
         if (threadIdx.x == 0) prefix[p.inFrags] = carry;
         total = carry;
+        // counts that cannot be (more keys than the input fragments hold): never index with them
+        if (total > p.inFrags * p.inCap) {
+            if (threadIdx.x == 0) atomicExch(&ctr->prjFallback, 1ull);
+            return;                                             // workgroup-uniform: carry is the same in every thread
+        }
     }
     if (total == 0) {                                           // the last chunks of a short relation
         if (threadIdx.x < p.fan) p.outCnt[(seg * p.fan + threadIdx.x) * p.C + local] = 0;

@@ -1,10 +1,8 @@
 #!/bin/bash
-# Development tool (GPU box): tools/time_prj.py once per tools/variants/*.so named.
+# Development tool (GPU box): tools/time_prj.py once per tools/variants/*.so named ("product" = the product library).
+# Variants are loaded by path (HJ_DEV_LIB_VARIANT, htm-hashjoin_amd/_lib.py); the product library is never touched.
 names=$1; shift
-lib=htm-hashjoin_amd/lib/libhtmjoin_hip.so
-cp $lib /tmp/libhtmjoin_hip.product.so
 for v in $names; do
-  cp tools/variants/$v.so $lib
-  timeout -k 10 300 python tools/time_prj.py --tag $v "$@" || echo "{\"tag\": \"$v\", \"error\": $?}"
+  if [ "$v" == "product" ]; then unset HJ_DEV_LIB_VARIANT; else export HJ_DEV_LIB_VARIANT=tools/variants/$v.so; fi
+  timeout -k 10 300 python tools/time_prj.py --tag $v "$@" 2>/dev/null || echo "{\"tag\": \"$v\", \"error\": $?}"
 done
-cp /tmp/libhtmjoin_hip.product.so $lib

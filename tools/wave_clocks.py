@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """When the wavefronts of k_build_wave start and finish (development tool; needs a library built with -DHJ_WV_CLOCKS:
-tools/mk_variant.sh clk hj_build_wave "-DHJ_WV_CLOCKS", copied over htm-hashjoin_amd/lib/libhtmjoin_hip.so).
+tools/mk_variant.sh clk hj_build_wave "-DHJ_WV_CLOCKS", loaded by path -- the product library is never touched).
 
-    python tools/wave_clocks.py --log2n 27 [--dist uniform:16]
+    HJ_DEV_LIB_VARIANT=tools/variants/clk.so python tools/wave_clocks.py --log2n 27 [--dist uniform:16]
 
 Prints, in microseconds from the first wavefront's start: percentiles of the start times, of the end times and of the
 durations over all chunks, and how many wavefronts are still running at 80 / 90 / 95 / 99 % of the kernel's span."""
@@ -17,7 +17,8 @@ ap.add_argument("--dist", default="uniform:16")
 a = ap.parse_args()
 n = 1 << a.log2n
 dist, w = a.dist.split(":")
-lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "htm-hashjoin_amd", "lib", "libhtmjoin_hip.so"))
+from htm_hashjoin_amd import _lib as _hjlib
+lib = ctypes.CDLL(_hjlib.LIB_PATH)            # the variant HJ_DEV_LIB_VARIANT names (it must export hj_debug_wave_clocks)
 with hj.HashJoinContext(0) as c:
     dR = c.dev_alloc(n * 8)
     R = hj.generate_data(dist, n, n, int(w)); c.copy_h2d(dR, R); del R
