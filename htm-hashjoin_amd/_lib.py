@@ -59,7 +59,8 @@ class hj_result(C.Structure):
             "clear_us", "build_us", "probe_us", "partition_us", "join_us", "total_us", "h2d_us")]
         + [("buildDeferred", C.c_uint64), ("buildPhaseA_us", C.c_double), ("algoUsed", C.c_uint32),
            ("prjPath", C.c_uint32), ("foreignTuples", C.c_uint64), ("prjScatterPass1R_us", C.c_double),
-           ("htmBuckets", C.c_uint64), ("htmOverflowBuckets", C.c_uint64), ("htmOverflowSum", C.c_uint64)]
+           ("htmBuckets", C.c_uint64), ("htmOverflowBuckets", C.c_uint64), ("htmOverflowSum", C.c_uint64),
+           ("compactFallback", C.c_uint64)]
     )
 
     def as_dict(self):

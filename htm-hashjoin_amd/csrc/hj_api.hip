@@ -315,7 +315,7 @@ int hj_reserve(hj_ctx* c, const hj_params* params, uint64_t rSize, uint64_t sSiz
     if (rSize > (1ull << 31)) return fail(c, HJ_ERR_INVALID, "hj_reserve: rSize > 2^31 per device");
     int rc = grow(c, c->table, c->tableCapSlots, 2 * rSize + kTableSlack);
     if (rc) return rc;
-    if (params->buildVariant > 3) return fail(c, HJ_ERR_INVALID, "hj_reserve: buildVariant must be 0, 1, 2 or 3");
+    if (params->buildVariant > 4) return fail(c, HJ_ERR_INVALID, "hj_reserve: buildVariant must be 0, 1, 2, 3 or 4");
     if (params->buildVariant != 1 && (own_supported(2 * rSize) || wave_supported(2 * rSize))) {
         // 1/8 headroom: a radix shard may receive slightly more than its nominal share (hj_build_keys_dev)
         const size_t ob = own_owner_bytes(2 * rSize);
@@ -364,45 +364,77 @@ static int build_common(hj_ctx* c, const void* d, bool key32, uint64_t n, uint32
     HJ_HIP(c, hipMemsetAsync(c->dCtr, 0, sizeof(Counters), c->stream));
     int rc;
     if ((rc = record(c, EV_CLEAR0))) return rc;
-    // which build kernel: 2 and 3 need their buffers (hj_reserve) and a table of at least one window / ring
+    // which build kernel: 2, 3 and 4 need their buffers (hj_reserve) and a table of at least one window / ring.
+    // 4 = the compact ring build (4-byte table, hj_build_wave.hip): what "rings" means whenever it can be tried; if it meets
+    // something it cannot handle, the classic ring build (3) enqueued behind it, gated on the device, redoes the table.
     uint32_t variant = c->forceVariant ? c->forceVariant : c->params.buildVariant;
     const bool canOwn = n && own_supported(tableSize) && c->capOwner >= own_owner_bytes(tableSize) &&
                         c->capQueue >= own_queue_bytes(n);
     const bool canWave = n && wave_supported(tableSize) && c->capQueue >= wave_queue_bytes(n, c->nCU);
+    const uint32_t pl = probe_len(c->params);
+    const bool canCompact = canWave && wave_compact_supported(tableSize, pl);
+    if (variant == 4 && !canCompact) variant = 3;
+    if (variant == 3 && c->forceVariant && canCompact) variant = 4;      // hj_join_dev(AUTO) sampled "rings": the compact ones first
     if (variant == 3 && !canWave) variant = canOwn ? 2 : 1;
     if (variant == 2 && !canOwn) variant = 1;
     if (variant == 0 && !canOwn && !canWave) variant = 1;
-    c->variantUsed = variant;                    // 0: decided on the device, reported from Counters::variant
+    c->variantUsed = (variant == 4) ? 0 : variant;     // 0: decided on the device (4 may fall back to 3), reported from Counters::variant
     c->algoUsed = c->params.algo == HJ_ALGO_AUTO ? (uint32_t)HJ_ALGO_ATOMIC : c->params.algo;
-    const uint32_t pl = probe_len(c->params);
+    const unsigned long long* word = &c->dCtr->variant;
     if (variant == 0) {
         // The locality pre-round decides ON THE DEVICE (this call stays asynchronous: no read-back). The kernels of
         // every candidate variant are enqueued behind it, each gated on the word the pre-round writes; the ones not
         // chosen return at once (~2 us each, less than the host round trip they replace). Order: the LDS builds
         // first, so that EV_BUILD_A still brackets the phase-A kernel of whichever of them runs.
         HJ_HIP(c, launch_sample_locality(d, key32, n, tableSize, hshift, 256, c->fitCount, c->stream));
-        launch_pick_variant(c->fitCount, canOwn, canWave, c->dCtr, c->stream);
+        launch_pick_variant(c->fitCount, canOwn, canWave, c->dCtr, c->stream, canCompact);
         HJ_HIP(c, hipGetLastError());
         if ((rc = record(c, EV_BUILD0))) return rc;
-        const unsigned long long* word = &c->dCtr->variant;
-        // phase A of both LDS variants, EV_BUILD_A, then their tails: the event brackets the phase-A kernel of
-        // whichever runs (plus one empty launch)
-        for (int parts = 1; parts <= 2; ++parts) {
-            if (canWave)
+        // phase A of the LDS variants, EV_BUILD_A, then their tails: the event brackets the phase-A kernel of
+        // whichever runs (plus the empty launches of the others)
+        if (canWave) {
+            HJ_HIP(c, launch_build_wave(d, key32, n, hshift, c->table, tableSize, pl, idxBase, c->sc, c->nCU, c->boundsBuf,
+                                        c->queueBuf, c->dCtr, Gate{word, 3, 4}, kWavePre, nullptr, c->stream));
+            if (canCompact)
                 HJ_HIP(c, launch_build_wave(d, key32, n, hshift, c->table, tableSize, pl, idxBase, c->sc, c->nCU, c->boundsBuf,
-                                            c->queueBuf, c->dCtr, Gate{word, 3}, parts, nullptr, c->stream));
-            if (canOwn)
-                HJ_HIP(c, launch_build_own(d, key32, n, hshift, c->table, tableSize, pl, idxBase, c->sc, c->nCU, c->ownerBuf,
-                                           c->queueBuf, c->queueCount, c->dCtr, Gate{word, 2}, parts, nullptr, c->stream));
-            if (parts == 1 && (rc = record(c, EV_BUILD_A))) return rc;
+                                            c->queueBuf, c->dCtr, Gate{word, 4}, kWaveMain, nullptr, c->stream, nullptr, kWaveCompact, 3));
+            HJ_HIP(c, launch_build_wave(d, key32, n, hshift, c->table, tableSize, pl, idxBase, c->sc, c->nCU, c->boundsBuf,
+                                        c->queueBuf, c->dCtr, Gate{word, 3}, kWaveMain, nullptr, c->stream));
         }
+        if (canOwn)
+            HJ_HIP(c, launch_build_own(d, key32, n, hshift, c->table, tableSize, pl, idxBase, c->sc, c->nCU, c->ownerBuf,
+                                       c->queueBuf, c->queueCount, c->dCtr, Gate{word, 2}, 1, nullptr, c->stream));
+        if ((rc = record(c, EV_BUILD_A))) return rc;
+        if (canWave) {
+            if (canCompact)
+                HJ_HIP(c, launch_build_wave(d, key32, n, hshift, c->table, tableSize, pl, idxBase, c->sc, c->nCU, c->boundsBuf,
+                                            c->queueBuf, c->dCtr, Gate{word, 4}, kWaveTail, nullptr, c->stream, nullptr, kWaveCompact, 3));
+            HJ_HIP(c, launch_build_wave(d, key32, n, hshift, c->table, tableSize, pl, idxBase, c->sc, c->nCU, c->boundsBuf,
+                                        c->queueBuf, c->dCtr, Gate{word, 3}, kWaveTail, nullptr, c->stream));
+        }
+        if (canOwn)
+            HJ_HIP(c, launch_build_own(d, key32, n, hshift, c->table, tableSize, pl, idxBase, c->sc, c->nCU, c->ownerBuf,
+                                       c->queueBuf, c->queueCount, c->dCtr, Gate{word, 2}, 2, nullptr, c->stream));
         launch_fill_empty(c->table, tableSize + kTableSlack, Gate{word, 1}, c->stream);
         launch_set_full_range(tableSize, c->dCtr, Gate{word, 1}, c->stream);
         launch_build_atomic_min(d, key32, n, c->table, tableSize, hshift, pl, idxBase, c->sc, c->dCtr, Gate{word, 1}, c->stream);
+    } else if (variant == 4) {
+        // the compact rings, asked for by the caller: the classic rings stay enqueued behind them as the gated fallback
+        launch_set_variant(c->dCtr, 4, c->stream);
+        if ((rc = record(c, EV_BUILD0))) return rc;
+        HJ_HIP(c, launch_build_wave(d, key32, n, hshift, c->table, tableSize, pl, idxBase, c->sc, c->nCU, c->boundsBuf,
+                                    c->queueBuf, c->dCtr, Gate{word, 4}, kWavePre | kWaveMain, nullptr, c->stream, nullptr, kWaveCompact, 3));
+        HJ_HIP(c, launch_build_wave(d, key32, n, hshift, c->table, tableSize, pl, idxBase, c->sc, c->nCU, c->boundsBuf,
+                                    c->queueBuf, c->dCtr, Gate{word, 3}, kWaveMain, c->ev[EV_BUILD_A], c->stream));
+        c->evSet[EV_BUILD_A] = true;
+        HJ_HIP(c, launch_build_wave(d, key32, n, hshift, c->table, tableSize, pl, idxBase, c->sc, c->nCU, c->boundsBuf,
+                                    c->queueBuf, c->dCtr, Gate{word, 4}, kWaveTail, nullptr, c->stream, nullptr, kWaveCompact, 3));
+        HJ_HIP(c, launch_build_wave(d, key32, n, hshift, c->table, tableSize, pl, idxBase, c->sc, c->nCU, c->boundsBuf,
+                                    c->queueBuf, c->dCtr, Gate{word, 3}, kWaveTail, nullptr, c->stream));
     } else if (variant == 3) {
         if ((rc = record(c, EV_BUILD0))) return rc;
         HJ_HIP(c, launch_build_wave(d, key32, n, hshift, c->table, tableSize, pl, idxBase, c->sc, c->nCU,
-                                    c->boundsBuf, c->queueBuf, c->dCtr, Gate{nullptr, 0}, 3, c->ev[EV_BUILD_A], c->stream));
+                                    c->boundsBuf, c->queueBuf, c->dCtr, Gate{nullptr, 0}, kWaveAll, c->ev[EV_BUILD_A], c->stream));
         c->evSet[EV_BUILD_A] = true;
     } else if (variant == 2) {
         if ((rc = record(c, EV_BUILD0))) return rc;
@@ -449,7 +481,7 @@ static int build_htm(hj_ctx* c, const uint64_t* dR, uint64_t rSize, uint64_t idx
     if (variant == 3) {
         if ((rc = record(c, EV_BUILD0))) return rc;
         HJ_HIP(c, launch_build_wave(dR, false, rSize, 0, c->table, slots, 3, idxBase, ShardCheck{0, 0, 0, 0}, c->nCU, c->boundsBuf,
-                                    c->queueBuf, c->dCtr, Gate{nullptr, 0}, 3, c->ev[EV_BUILD_A], c->stream, c->htmConflicts));
+                                    c->queueBuf, c->dCtr, Gate{nullptr, 0}, kWaveAll, c->ev[EV_BUILD_A], c->stream, c->htmConflicts));
         c->evSet[EV_BUILD_A] = true;
     } else {
         launch_fill_empty(c->table, slots + kTableSlack, Gate{nullptr, 0}, c->stream);
@@ -658,6 +690,7 @@ int hj_fetch_result(hj_ctx* c, hj_result* out)
             out->outputSum = k.tableSumFull + k.htmOverflowSum;
         }
         out->buildVariant = c->variantUsed ? c->variantUsed : (uint32_t)k.variant;   // 0: the device chose
+        out->compactFallback = k.compactFail;
         out->buildDeferred = k.deferred;
         out->buildPhaseA_us = elapsed_us(c, EV_BUILD0, EV_BUILD_A);
         out->clear_us = elapsed_us(c, EV_CLEAR0, EV_BUILD0);
@@ -679,13 +712,24 @@ int hj_export_table(hj_ctx* c, uint64_t* host_table, uint64_t tableSize)
     if (!c || !host_table) return HJ_ERR_INVALID;
     if (!c->built || c->htmBuilt || tableSize != c->tableSize) return fail(c, HJ_ERR_STATE, "hj_export_table: no open-addressing table of that size");
     HJ_HIP(c, hipSetDevice(c->device));
-    HJ_HIP(c, hipMemcpyAsync(host_table, c->table, tableSize * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HJ_HIP(c, hipStreamSynchronize(c->stream));
-    // device format (index << 32 | key, all ones = empty) -> reference format (key, 0 = empty)
-    // only [validLo, validHiEx + 512) holds defined values (hj_device.h); the rest is empty by definition
     Counters k;
     HJ_HIP(c, hipMemcpy(&k, c->dCtr, sizeof(k), hipMemcpyDeviceToHost));
+    // only [validLo, validHiEx + 512) holds defined values (hj_device.h); the rest is empty by definition
     const uint64_t lo = k.validLo, hi = k.validHiEx + 512 < tableSize ? k.validHiEx + 512 : tableSize;
+    if (k.tableFormat == kFormatKeys4) {
+        // compact device format (4-byte keys, 0xFFFFFFFF = empty) -> reference format (key, 0 = empty): the keys land in
+        // the upper half of the caller's buffer and are widened from the front (the write position never passes the read one)
+        uint32_t* keys = reinterpret_cast<uint32_t*>(host_table) + tableSize;
+        HJ_HIP(c, hipMemcpy(keys, c->table, tableSize * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < tableSize; ++i) {
+            const uint32_t v = keys[i];
+            host_table[i] = (i < lo || i >= hi || v == 0xFFFFFFFFu) ? 0 : v;
+        }
+        return HJ_OK;
+    }
+    HJ_HIP(c, hipMemcpy(host_table, c->table, tableSize * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    // device format (index << 32 | key, all ones = empty) -> reference format (key, 0 = empty)
     for (uint64_t i = 0; i < tableSize; ++i)
         host_table[i] = (i < lo || i >= hi || host_table[i] == kEmpty) ? 0 : (uint32_t)host_table[i];
     return HJ_OK;

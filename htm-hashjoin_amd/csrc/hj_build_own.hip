@@ -681,14 +681,14 @@ void launch_build_deferred(const void* queueBuf, const unsigned long long* queue
                        static_cast<const DeferredEntry*>(queueBuf), queueCount, table, tableSize - 1, hshift, probeLen, ctr, gate);
 }
 
-__global__ void k_pick_variant(const unsigned int* __restrict__ fit, bool canOwn, bool canWave, Counters* __restrict__ ctr)
+__global__ void k_pick_variant(const unsigned int* __restrict__ fit, bool canOwn, bool canWave, bool canCompact, Counters* __restrict__ ctr)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) ctr->variant = variant_for_sample(fit[0], fit[1], fit[2], canOwn, canWave);
+    if (threadIdx.x == 0 && blockIdx.x == 0) ctr->variant = variant_for_sample(fit[0], fit[1], fit[2], canOwn, canWave, canCompact);
 }
 
-void launch_pick_variant(const unsigned int* fitCount, bool canOwn, bool canWave, Counters* ctr, hipStream_t s)
+void launch_pick_variant(const unsigned int* fitCount, bool canOwn, bool canWave, Counters* ctr, hipStream_t s, bool canCompact)
 {
-    hipLaunchKernelGGL(k_pick_variant, dim3(1), dim3(64), 0, s, fitCount, canOwn, canWave, ctr);
+    hipLaunchKernelGGL(k_pick_variant, dim3(1), dim3(64), 0, s, fitCount, canOwn, canWave, canCompact, ctr);
 }
 
 }  // namespace hj

@@ -85,6 +85,9 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 #ifndef HJ_WV_ALLIN
 #define HJ_WV_ALLIN 1                               // 1: tiles wholly inside ring and range skip the per-tuple ring test
 #endif
+#ifndef HJ_WV_REQUEUE_FRONT
+#define HJ_WV_REQUEUE_FRONT 1                       // 1: unfinished retry entries return to the queue's front (0: to its tail)
+#endif
 #ifndef HJ_WV_CARRY
 #define HJ_WV_CARRY 1                               // 1: leave < 64 retry entries queued across tiles
 #endif
@@ -106,6 +109,10 @@ static_assert(kWvQCap >= 128 && (kWvQCap & (kWvQCap - 1)) == 0, "FIFO ring: a po
 constexpr size_t kWvLdsBytes = (size_t)kWvWaves * (kWvWin * sizeof(uint64_t) + 3 * kWvQCap * sizeof(uint32_t));
 
 __device__ __forceinline__ uint64_t wv_pack(uint32_t hi, uint32_t lo) { return ((uint64_t)hi << 32) | lo; }
+// The lane mask of a condition. HIP's __ballot(int) compares an INTEGER with zero: a condition that already is a lane mask
+// (every compare produces one) is first turned into 0 / 1 per lane and compared again -- two vector instructions per
+// ballot, ~50 per tile in a kernel whose retry rounds are bound by vector issue. This form takes the mask as it is.
+__device__ __forceinline__ unsigned long long wv_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 // minimum over the wavefront, result wave-uniform: four DPP steps inside each row of 16, then the four rows
 __device__ __forceinline__ uint32_t wave_umin(uint32_t v)
@@ -135,11 +142,16 @@ __device__ __forceinline__ uint32_t wave_umin(uint32_t v)
 // belong below it are taken by the previous wavefront, which reads kWvOverlap positions past its own end. Without
 // this every seam cost ~70 deferred tuples on `uniform` (half a granule's worth), each a cascade of global atomics.
 // starts[c] = q (or p if no crossing shows up: many tuples per granule), raw[c] = the granule (kNone: no valid tuple).
-constexpr uint32_t kWvLook = 512;
+constexpr uint32_t kWvLook = 256;
 #ifndef HJ_WV_OVERLAP
 #define HJ_WV_OVERLAP 64
 #endif
 constexpr uint32_t kWvOverlap = HJ_WV_OVERLAP;
+// COMPACT build: positions before its seam a wavefront also reads (shadow zone), so that shadow zone + head zone are
+// exactly its first tile; and the crossers one seam may let in before the build gives up on the compact table
+constexpr uint32_t kWvShadow = 64 * HJ_WV_PER - HJ_WV_OVERLAP;
+constexpr uint32_t kWvTail = HJ_WV_OVERLAP;      // the last positions of a chunk whose next-range tuples the NEXT wavefront inserts
+constexpr uint32_t kWvPredCap = 64;
 template <bool KEY32, bool HTM>
 __global__ void __launch_bounds__(kBlock)
 k_wave_seams(const void* __restrict__ Rv, uint64_t n, uint32_t chunkLen, uint32_t nChunks, uint64_t mask,
@@ -153,62 +165,83 @@ k_wave_seams(const void* __restrict__ Rv, uint64_t n, uint32_t chunkLen, uint32_
     if (c > nChunks) return;
     if (c == nChunks) { if (lane == 0) starts[c] = (uint32_t)n; return; }
     const uint64_t p = (uint64_t)c * chunkLen;
-    uint32_t h[kWvLook / 64];
-#pragma unroll
-    for (uint32_t k = 0; k < kWvLook / 64; ++k) {
-        const uint64_t i = p + 64 * k + lane;
-        h[k] = kNone;
-        if (i < n) {
-            const uint64_t t = R[i];
-            if ((t >> 32) == 0 && t != 0) h[k] = home32<HTM>((uint32_t)t, hshift, (uint32_t)mask);
-        }
-    }
-    const uint32_t m = wave_umin(h[0]);
+    // The look proceeds in steps of 128 tuples (two loads per lane) and stops at the first crossing: on the reference's
+    // inputs one or two steps do (a granule is 128 slots), and the pre-pass reads 1-2 KiB per seam instead of 4 KiB
+    // (32768 seams at 2^30: the full look was 134 MB of reads, 35 us).
+    auto load_home = [&](uint64_t i) -> uint32_t {
+        if (i >= n) return kNone;
+        const uint64_t t = R[i];
+        return ((t >> 32) == 0 && t != 0) ? home32<HTM>((uint32_t)t, hshift, (uint32_t)mask) : kNone;
+    };
+    uint32_t h0 = load_home(p + lane), h1 = load_home(p + 64 + lane);
+    const uint32_t m = wave_umin(h0);
     uint32_t start = (uint32_t)p, g = m == kNone ? kNone : m >> kGranShift;
     if (c > 0 && m != kNone) {
         const uint32_t edge = ((m >> kGranShift) + 1) << kGranShift;          // first slot of the next granule (0 on wrap: no crossing)
-        bool found = false;
-#pragma unroll
-        for (uint32_t k = 0; k < kWvLook / 64; ++k) {
-            const unsigned long long hit = __ballot(h[k] != kNone && h[k] >= edge && edge != 0);
-            if (!found && hit) {
-                found = true;
-                start = (uint32_t)(p + 64 * k + (uint32_t)__ffsll((long long)hit) - 1);
+        for (uint32_t k = 0; k < kWvLook / 64 && edge != 0; k += 2) {
+            if (k) { h0 = load_home(p + 64 * k + lane); h1 = load_home(p + 64 * (k + 1) + lane); }
+            const unsigned long long hit0 = wv_ballot(h0 != kNone && h0 >= edge), hit1 = wv_ballot(h1 != kNone && h1 >= edge);
+            if (hit0 | hit1) {
+                start = hit0 ? (uint32_t)(p + 64 * k + (uint32_t)__ffsll((long long)hit0) - 1)
+                             : (uint32_t)(p + 64 * (k + 1) + (uint32_t)__ffsll((long long)hit1) - 1);
                 g = edge >> kGranShift;
+                break;
             }
         }
     }
     if (lane == 0) { starts[c] = start; raw[c] = g; }
 }
 
-// bounds[c] = max over chunks <= c of raw (chunks without a valid sample inherit), bounds[nChunks] = the table's
-// end. One workgroup: every thread takes a run of consecutive chunks, the runs' maxima are scanned through LDS.
+// bounds[c] = max over chunks <= c of raw (chunks without a valid sample inherit; chunks before the first valid sample
+// take the first one's: nothing below it is owned), bounds[nChunks] = the table's end. Every workgroup takes kBlock
+// consecutive chunks and finds the maximum over all chunks before its own by itself (coalesced reads of an array of at most
+// 128 KiB that sits in L2) -- no second kernel, no look-back chain; the single-workgroup version of round 2 took 60 us
+// for 32768 chunks.
 __global__ void __launch_bounds__(kBlock)
 k_wave_bounds_scan(const uint32_t* __restrict__ raw, uint32_t nChunks, uint32_t numGran, uint32_t* __restrict__ bounds, Gate gate)
 {
     if (gate_closed(gate)) return;
-    __shared__ uint32_t runMax[kBlock], sFirst;
-    const uint32_t t = threadIdx.x;
-    const uint32_t per = (nChunks + kBlock - 1) / kBlock, b = t * per, e = b + per < nChunks ? b + per : nChunks;
-    if (t == 0) sFirst = kNone;
-    __syncthreads();
-    // the first valid sample opens the first range (nothing below it is owned): lowest chunk index with a sample
-    uint32_t firstIdx = kNone, m = 0;
-    for (uint32_t c = b; c < e; ++c) {
-        const uint32_t v = raw[c];
-        if (v != kNone) { if (firstIdx == kNone) firstIdx = c; m = v > m ? v : m; }
+    __shared__ uint32_t wmax[kBlock / 64], wscan[kBlock / 64];
+    const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const uint32_t base = blockIdx.x * kBlock, c = base + t;
+    // maximum over the valid samples of every chunk before this workgroup's (kNone = no sample = contributes nothing)
+    uint32_t before = 0;
+    bool any = false;
+    for (uint32_t k = t; k < base; k += kBlock) {
+        const uint32_t v = raw[k];
+        before = (v != kNone && v > before) ? v : before;
+        any |= v != kNone;
     }
-    if (firstIdx != kNone) atomicMin(&sFirst, firstIdx);
-    runMax[t] = m;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(before, off, 64); before = o > before ? o : before; }
+    const unsigned long long anyW = wv_ballot(any);
+    if (lane == 0) { wmax[w] = before; wscan[w] = anyW ? 1u : 0u; }
     __syncthreads();
-    uint32_t run = sFirst == kNone ? 0u : raw[sFirst];
-    for (uint32_t k = 0; k < t; ++k) run = runMax[k] > run ? runMax[k] : run;      // <= 255 LDS reads per thread
-    for (uint32_t c = b; c < e; ++c) {
-        const uint32_t v = raw[c];
-        if (v != kNone && v > run) run = v;
+    uint32_t run = 0; bool have = false;
+    for (int k = 0; k < kBlock / 64; ++k) { run = wmax[k] > run ? wmax[k] : run; have |= wscan[k] != 0; }
+    __syncthreads();
+    // inclusive prefix maximum inside the workgroup
+    const uint32_t v = c < nChunks ? raw[c] : kNone;
+    uint32_t inc = v == kNone ? 0u : v;
+    const unsigned long long validMask = wv_ballot(v != kNone);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(inc, off, 64); if ((int)lane >= off) inc = o > inc ? o : inc; }
+    if (lane == 63) wmax[w] = inc;
+    if (lane == 0) wscan[w] = validMask ? 1u : 0u;
+    __syncthreads();
+    bool haveHere = have || (validMask & ((2ull << lane) - 1ull)) != 0;
+    for (uint32_t k = 0; k < w; ++k) { run = wmax[k] > run ? wmax[k] : run; haveHere |= wscan[k] != 0; }
+    run = inc > run ? inc : run;
+    if (c < nChunks) {
+        if (!haveHere) {
+            // no valid sample up to this chunk: the first valid one after it opens the first range (a relation that
+            // starts with invalid tuples: rare, and the walk is short)
+            run = 0;
+            for (uint32_t k = c + 1; k < nChunks; ++k) { const uint32_t x = raw[k]; if (x != kNone) { run = x; break; } }
+        }
         bounds[c] = run < numGran ? run : numGran;
     }
-    if (t == 0) bounds[nChunks] = numGran;
+    if (blockIdx.x == 0 && t == 0) bounds[nChunks] = numGran;
 }
 
 #ifdef HJ_WV_CLOCKS
@@ -222,19 +255,47 @@ extern "C" int hj_debug_wave_clocks(uint32_t* out, uint32_t nChunks)
 #endif
 
 // ---- the build ------------------------------------------------------------------------------------------------
-template <bool KEY32, bool CHECK, bool HTM>
-__global__ void __launch_bounds__(kWvThreads, HJ_WV_WPE)
+// COMPACT (the fast path of the open-addressing table, hj_device.h "table formats"): the ring still holds (index << 32 | key),
+// but what leaves for HBM is the KEY WORD alone -- 4 bytes per slot instead of 8, and the probe reads 4 bytes per slot too.
+// The index words exist only to order the inserts, and inside a wavefront's ring they have done that by the time a granule
+// retires; nothing after this kernel may therefore need them: there is no deferred phase. Every way a tuple used to get
+// deferred is either handled here or raises Counters::compactFail, after which the classic 8-byte build (gated on the word
+// k_wave_decide rewrites) redoes the whole table:
+//   * walks that cross the seam into the next wavefront's range ("crossers", ~1.6 per seam on `uniform`): wavefront c
+//     ALSO inserts, into a shadow granule below its range that it never writes out, the tuples whose home slot lies in
+//     the last 128 slots of wavefront c-1's range (it reads kWvShadow positions before its seam for them), and so sees
+//     for itself which of them walk across. Influence only flows towards higher slots, so c-1's own range never depends
+//     on c's. Whether the shadow saw the truth is CHECKED, not assumed: c-1 lists the tuples that really left its range
+//     at the seam, c lists the ones it let in, k_wave_validate compares the two lists seam by seam (equal lists = one
+//     consistent run of the protocol over both ranges = the unique fixed point).
+//   * retry entries the ring is about to leave behind get their rounds before it moves (forced rounds);
+//   * anything else (a key far from its neighbours, a walk that wraps around the table end, key 0xFFFFFFFF = the compact
+//     empty pattern) raises the flag.
+template <bool KEY32, bool CHECK, bool HTM, bool COMPACT>
+#ifndef HJ_WV_WPE_COMPACT
+#define HJ_WV_WPE_COMPACT 4                         // COMPACT: wavefronts per SIMD the registers must allow (115 VGPRs once the chunk state is scalar)
+#endif
+__global__ void __launch_bounds__(kWvThreads, COMPACT ? HJ_WV_WPE_COMPACT : HJ_WV_WPE)
 k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_t nChunks, const uint32_t* __restrict__ starts,
              const uint32_t* __restrict__ bounds, uint64_t* __restrict__ table, uint64_t mask, uint32_t hshift,
              uint32_t probeLen, uint64_t idxBase, ShardCheck sc, DeferredEntry* __restrict__ queue,
              uint32_t* __restrict__ dcounts, Counters* __restrict__ ctr, Gate gate, uint64_t* __restrict__ htmConflicts,
-             uint32_t* __restrict__ ccounts)
+             uint32_t* __restrict__ ccounts, uint32_t residentWG, uint32_t* __restrict__ pcounts)
 {
+    static_assert(!(COMPACT && HTM), "the bucketised table keeps its own layout");
     if (gate_closed(gate)) return;
     extern __shared__ __align__(16) uint64_t lds[];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wavefront's number inside the workgroup is the same in all its lanes, but the compiler only knows that when told:
+    // everything derived from the chunk number (its seams, its slot range, the ring's position, every test against them) then
+    // lives in scalar registers and is computed by the scalar unit -- the vector unit is what this kernel runs out of
+    const uint32_t lane = threadIdx.x & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t c = blockIdx.x * kWvWaves + wave;
     if (c >= nChunks) return;                                            // whole wavefronts leave; nobody waits for them
+    if constexpr (COMPACT) {
+        // some wavefront has met an input the compact table cannot take: the classic build will redo everything,
+        // whatever is written from here on is never looked at (k_wave_decide reads the flag before anything else)
+        if (*reinterpret_cast<volatile unsigned long long*>(&ctr->compactFail)) return;
+    }
 #ifdef HJ_WV_CLOCKS
     if (lane == 0 && c < 65536) g_wvClk[2 * c] = (uint32_t)wall_clock64();
 #endif
@@ -244,33 +305,61 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
     uint32_t* const myQHi = myQLo + kWvQCap;
 
 #if HJ_WV_PRIO
-    // workgroups per quarter of the first, resident round (a 256-CU device assumed: only the fairness of the rotation depends on it)
-    constexpr uint32_t kResidentWG = (uint32_t)HJ_WV_WAVES_PER_CU * 256u / (uint32_t)kWvWaves;
-    const uint32_t prioDiv = ((gridDim.x <= kResidentWG ? gridDim.x : kResidentWG) + 3u) / 4u;
+    // workgroups per quarter of the first, resident round (residentWG = what this device holds at once, from the launch)
+    const uint32_t prioDiv = ((gridDim.x <= residentWG ? gridDim.x : residentWG) + 3u) / 4u;
 #endif
-    const uint64_t cb = starts[c];
+    const bool lastChunk = c + 1 == nChunks;
+    const uint64_t cb0 = starts[c];
     const uint32_t clen = starts[c + 1] - starts[c];                     // the chunk proper: its tuples are counted here
+    // COMPACT: the kWvShadow positions before the seam are read too (shadow zone, see above); every offset below is
+    // relative to the first position READ, cb = cb0 - S, and the chunk proper is [S, S + clen)
+    const uint32_t S = (COMPACT && c) ? (cb0 < kWvShadow ? (uint32_t)cb0 : kWvShadow) : 0u;
+    const uint64_t cb = cb0 - S;
+    const uint32_t cend = S + clen;
+    // COMPACT: tuples of the NEXT range that sit before the seam ("early arrivals": keys a little ahead of their neighbours)
+    // are left to the next wavefront, which reads those positions anyway (its shadow zone). Where they can sit is known
+    // from the NOMINAL seam alone, which both sides know: the pre-pass moved the real seam forward from it by less than
+    // kWvLook positions, to the first position of the next range -- so early arrivals lie before the nominal seam, a shuffle
+    // window's length at most; the zone starts kWvTail positions before it. [tailFrom, cend): my tail zone;
+    // [claimFrom, S): the previous chunk's tail zone as I see it.
+    const uint32_t chunkLenNom = sliceLen - kWvLook - kWvOverlap;
+    const uint32_t tailFrom = (COMPACT && !lastChunk) ? (uint32_t)((uint64_t)(c + 1) * chunkLenNom - cb) - kWvTail : 0xFFFFFFFFu;
+    const uint32_t claimFrom = (COMPACT && c) ? (uint32_t)((uint64_t)c * chunkLenNom - cb) - kWvTail : 0u;
+    static_assert(kWvShadow >= kWvLook + kWvTail, "the shadow zone reaches back past the previous chunk's tail zone");
+    (void)tailFrom; (void)claimFrom;
     // ... and kWvOverlap positions of the next chunk are read too: its stragglers below the seam are inserted here
-    const uint32_t plen = (uint32_t)((cb + clen + kWvOverlap < n ? cb + clen + kWvOverlap : n) - cb);
+    const uint32_t plen = (uint32_t)((cb + cend + kWvOverlap < n ? cb + cend + kWvOverlap : n) - cb);
     const uint32_t mask32 = (uint32_t)mask;
     const uint32_t numGran = (uint32_t)((mask + 1) >> kGranShift);
     if constexpr (!KEY32) hshift = 0u;            // 8-byte tuples always hash with shift 0 (launch_build_wave checks): one shift less per home slot
     using Elem = typename std::conditional<KEY32, uint32_t, uint64_t>::type;
     const Elem* __restrict__ Rc = static_cast<const Elem*>(Rv) + cb;
     const uint32_t idx0 = (uint32_t)(idxBase + cb);
-    const bool lastChunk = c + 1 == nChunks;
     // this wavefront's slot range, in granules: [loG, limG). The last chunk's range is open up to the table's end;
     // how far it got is published below (ownHiEx).
     const uint32_t loG = bounds[c];
     const uint32_t limG = lastChunk ? numGran : bounds[c + 1];
     const uint32_t loSlot = c ? loG << kGranShift : 0u;                 // head zone: tuples below it are the previous wavefront's
     const uint32_t limSlot = limG << kGranShift;                        // overlap zone: only tuples below it are mine (0 = 2^32: table end)
+    // COMPACT: the shadow granule [shadowLo, loSlot) of the previous wavefront's range is simulated here, never written
+    bool shadowOn = COMPACT && S != 0 && loG != 0;  // wave-uniform: the shadow granule is still in the ring (the first tile and its rounds)
+    uint32_t pCount = 0;                         // COMPACT: crossers let in at the seam so far (wave-uniform)
+    // COMPACT: something only the classic build can handle raises Counters::compactFail at once (a rare path: no register is
+    // kept for it); the per-tuple tests of classify() collect in one lane mask that is looked at once per tile
+    auto raise = [&](bool cond, unsigned long long why) {
+        if (wv_ballot(cond) && lane == 0) atomicOr(&ctr->compactFail, why);
+    };
+    bool ffSeen = false;                         // a key equal to the compact empty pattern
+    (void)pCount; (void)ffSeen;
 
     for (uint32_t i = lane; i < kWvWin / 2; i += 64) reinterpret_cast<ulonglong2*>(win)[i] = make_ulonglong2(kEmpty, kEmpty);
 
-    uint32_t winLoG = loG;                       // ring = granules [winLoG, winLoG + kWvGran), wave-uniform
+    uint32_t winLoG = shadowOn ? loG - 1 : loG;  // ring = granules [winLoG, winLoG + kWvGran), wave-uniform
     uint32_t qCount = 0, qHead = 0;              // retry queue (FIFO ring): entries and position of the oldest, wave-uniform
     uint32_t rounds = 0;                         // retry rounds so far (wave-uniform)
+#ifdef HJ_WV_STATS
+    uint32_t forcedRounds = 0;                   // development builds: rounds forced by the ring's movement; reported through `deferred`
+#endif
     unsigned long long dropSum = 0, inSum = 0;
     uint32_t drops = 0, bad = 0, foreign = 0;
     uint32_t dCount = 0;                         // tuples deferred so far (wave-uniform)
@@ -287,14 +376,17 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
             const ulonglong2 t = *src;
 #if defined(HJ_WV_ABL_NOSTORE)
             if (t.x == 0x1234567ull) table[lane] = t.y;        // ablation (development builds): the retire stores never happen
-#elif defined(HJ_WV_ABL_HALFSTORE)
-            {   // ablation: 4 bytes per slot leave (the key words), 512 B per granule
-                typedef unsigned int u2 __attribute__((ext_vector_type(2)));
-                u2 vv; vv.x = (uint32_t)t.x; vv.y = (uint32_t)t.y;
-                __builtin_nontemporal_store(vv, reinterpret_cast<u2*>(reinterpret_cast<uint32_t*>(table) + ((uint64_t)winLoG << kGranShift)) + lane);
-            }
 #else
-            {   // written once and not read again by this kernel: nontemporal stores (-1.5 % kernel time at 2^30, and
+            if constexpr (COMPACT) {
+                // the key words alone leave: 512 bytes per granule (the empty pattern's low word is the compact empty
+                // pattern); the shadow granule belongs to the previous wavefront and is not written
+                if (winLoG >= loG) {
+                    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+                    u2 vv; vv.x = (uint32_t)t.x; vv.y = (uint32_t)t.y;
+                    __builtin_nontemporal_store(vv, reinterpret_cast<u2*>(reinterpret_cast<uint32_t*>(table) + ((uint64_t)winLoG << kGranShift)) + lane);
+                }
+            } else {
+                // written once and not read again by this kernel: nontemporal stores (-1.5 % kernel time at 2^30, and
                 // the probe that follows runs 1 % faster; nontemporal LOADS of R were slower)
                 typedef unsigned long long v2 __attribute__((ext_vector_type(2)));
                 v2 vv; vv.x = t.x; vv.y = t.y;
@@ -316,7 +408,25 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
     // deferred; returns "not finished" with the entry's next state in place.
     auto round_body = [&](uint32_t& pos, uint32_t& mlo, uint32_t& mhi, const bool has) -> bool {
         const uint32_t key = mlo;
-        uint32_t budget = probeLen - ((pos - home32<HTM>(key, hshift, mask32)) & mask32);
+        const uint32_t homeOfKey = home32<HTM>(key, hshift, mask32);
+        uint32_t budget = probeLen - ((pos - homeOfKey) & mask32);
+        if constexpr (COMPACT) {
+            // a tuple of the shadow granule arriving at my first slot: a crosser I let in (each passes pos == loSlot
+            // exactly once: walks advance slot by slot, and the look never skips across a granule boundary)
+            if (shadowOn) {
+                const bool cross = has & (pos == loSlot) & (homeOfKey < loSlot) & (budget != 0);
+                const unsigned long long xm = wv_ballot(cross);
+                if (xm) {
+                    const uint32_t at = pCount + lane_rank(xm);
+                    // the list lives at the end of this chunk's slice of the deferred queue (which the compact build otherwise
+                    // uses for the handful of crossers that leave the range): kWvPredCap 8-byte entries
+                    uint64_t* const myPred = reinterpret_cast<uint64_t*>(queue + (uint64_t)(c + 1) * sliceLen) - kWvPredCap;
+                    if (cross & (at < kWvPredCap)) myPred[at] = wv_pack(mhi, mlo);
+                    raise(cross & (at >= kWvPredCap), 2ull);
+                    pCount += (uint32_t)__popcll(xm);
+                }
+            }
+        }
         const bool ownOk = in_ring(pos);
         const bool drop0 = has & (budget == 0);
         const bool toDefer = has & !drop0 & !ownOk;
@@ -356,10 +466,15 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
         const bool disp = fail & (old > mine);                             // displaced a later tuple: carry it on
 #endif
         mlo = disp ? (uint32_t)old : mlo; mhi = disp ? (uint32_t)(old >> 32) : mhi;
-        const bool dropped = drop0 | drop1;
+        bool dropped = drop0 | drop1;
+        if constexpr (COMPACT) {
+            // a shadow tuple that runs out of budget BELOW my range is the previous wavefront's conflict, not mine; one that
+            // tried a slot of my range first (its last try is home + probeLen - 1) came in as a crosser and is mine
+            if (shadowOn) dropped = dropped & ((homeOfKey >= loSlot) | (homeOfKey + (probeLen - 1u) >= loSlot));
+        }
         drops += dropped ? 1u : 0u; dropSum += dropped ? (unsigned long long)key : 0ull;
         if constexpr (HTM) {       // the bucket is full: the tuple is one of the reference's conflicts (HTMHashBuild.hpp:181-183)
-            const unsigned long long cm = __ballot(dropped);
+            const unsigned long long cm = wv_ballot(dropped);
             if (cm) {
                 if (dropped) myConflicts[cCount + lane_rank(cm)] = mine;
                 cCount += (uint32_t)__popcll(cm);
@@ -368,8 +483,19 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
         // deferred tuples go to this wavefront's OWN slice of the deferred queue, [cb, cb + clen): a tuple leaves at
         // most once, so the slice cannot overflow, and no atomic is needed to place it (a returning global atomic
         // per round with a straggler stalled the wavefront for microseconds)
-        const unsigned long long dm = __ballot(toDefer);
+        const unsigned long long dm = wv_ballot(toDefer);
         if (dm) {
+            if constexpr (COMPACT) {
+                // no deferred phase: a walk that leaves my range at the seam is listed for the check against what the
+                // next wavefront let in (it has inserted the tuple itself); everything else only the classic build can do
+                const bool crosser = toDefer & (pos == limSlot) & (homeOfKey < limSlot) & !lastChunk;
+                const unsigned long long cmk = wv_ballot(crosser);
+                raise(toDefer & !crosser, 1ull);
+                if (cmk) {
+                    if (crosser) myDeferred[dCount + lane_rank(cmk)].packed = mine;
+                    dCount += (uint32_t)__popcll(cmk);
+                }
+            } else {
             if (toDefer) {
                 DeferredEntry* q = myDeferred + dCount + lane_rank(dm);
                 q->pos = pos; q->packed = mine;
@@ -377,6 +503,7 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
                 usedLo = db < usedLo ? db : usedLo; usedHi1 = db + 1 > usedHi1 ? db + 1 : usedHi1;
             }
             dCount += (uint32_t)__popcll(dm);
+            }
         }
         pos = fail ? ((pos + 1) & mask32) : pos;
         return recheck | fail;
@@ -394,12 +521,26 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
         qHead = (qHead + take) & (kWvQCap - 1);
         qCount -= take;
         const bool again = round_body(pos, mlo, mhi, has);
-        const unsigned long long am = __ballot(again);
+        const unsigned long long am = wv_ballot(again);
+#if HJ_WV_REQUEUE_FRONT
+        // what did not finish goes back to the queue's FRONT: an entry then gets its (at most probeLength) rounds one after
+        // the other and is done while its slots are still far from the ring's tail, instead of waiting behind a tile's
+        // worth of newer entries (COMPACT has no deferred phase: an entry the ring is about to leave behind costs a
+        // forced round, below)
+        const uint32_t back = (uint32_t)__popcll(am);
+        qHead = (qHead - back) & (kWvQCap - 1);
+        if (again) {
+            const uint32_t at = (qHead + lane_rank(am)) & (kWvQCap - 1);
+            myQPos[at] = pos; myQLo[at] = mlo; myQHi[at] = mhi;
+        }
+        qCount += back;
+#else
         if (again) {
             const uint32_t at = (qHead + qCount + lane_rank(am)) & (kWvQCap - 1);
             myQPos[at] = pos; myQLo[at] = mlo; myQHi[at] = mhi;
         }
         qCount += (uint32_t)__popcll(am);
+#endif
         ++rounds;
     };
     // to completion: dense rounds while more than a wavefront's worth is queued, then the last <= 64 entries stay in
@@ -410,7 +551,7 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
         const uint32_t at0 = (qHead + lane) & (kWvQCap - 1);
         uint32_t pos = myQPos[at0], mlo = myQLo[at0], mhi = myQHi[at0];
         qCount = 0;
-        while (__ballot(act)) act = round_body(pos, mlo, mhi, act);
+        while (wv_ballot(act)) act = round_body(pos, mlo, mhi, act);
     };
 
     // tile t covers chunk offsets [t * kWvTile, ...); lane's tuple j sits at offset t * kWvTile + 64 j + lane
@@ -427,6 +568,11 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
 #pragma unroll
     for (int p = 0; p < kWvPf; ++p) issue(nxt[p], (uint32_t)p * kWvTile);
 
+    // COMPACT: lowest / highest home slot of the tile about to start, taken from its keys at the end of the tile before it
+    // (forced rounds, below); only for full tiles
+    uint32_t tminF = kNone, tmaxF = 0;
+    (void)tminF; (void)tmaxF;
+    static_assert(!COMPACT || kWvPf == 1, "the forced rounds look one tile ahead");
     for (uint32_t tb0 = 0; tb0 < plen; tb0 += kWvPf * kWvTile) {
 #pragma unroll
       for (int p = 0; p < kWvPf; ++p) {
@@ -462,7 +608,8 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
             }
         }
 #endif
-        const bool full = (tb + kWvTile <= clen) & (tb >= kWvOverlap);   // wave-uniform: no head zone, no overlap zone
+        // wave-uniform: no shadow / head zone, no overlap zone (COMPACT: and no tail zone)
+        const bool full = (tb + kWvTile <= (cend < tailFrom ? cend : tailFrom)) & (tb >= S + kWvOverlap);
         issue(nxt[p], tb + kWvPf * kWvTile);
         const uint32_t roundsAtTileStart = rounds;
         (void)roundsAtTileStart;
@@ -475,25 +622,76 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
         // FULL tiles (every position is this chunk's own, no seam zone) skip the zone tests: they are all but the
         // first and the last one or two tiles of a chunk
         uint32_t badTile = 0;                                         // wave-uniform: invalid tuples of a full tile
+        // COMPACT, first and last tiles of a chunk: which of the tile's tuples are inserted here (bit j) and counted here
+        // (bit 8 + j). The zone tests are many, and unrolled over the tile's eight tuples per lane their lane masks took ~40
+        // scalar registers more than the kernel has (spilled to vector lanes all over the hot path); so this cold path
+        // takes the tuples one at a time in a rolled loop, re-reading the keys (cache hits).
+        uint32_t zb = 0;
+        (void)zb;
+        if constexpr (COMPACT) {
+            if (!full) {
+#pragma unroll 1
+                for (int j = 0; j < kWvPer; ++j) {
+                    const uint32_t o = tb + lane + 64 * j;
+                    const Elem t = o < plen ? Rc[o] : (Elem)0;
+                    const uint32_t key = (uint32_t)t;
+                    const bool okKey = (KEY32 || (uint32_t)((uint64_t)t >> 32) == 0) & (key != 0);
+                    const uint32_t h = home32<HTM>(key, hshift, mask32);
+                    const bool in = (o >= S) & (o < cend);
+                    // inserted here: my tuples, except head-zone stragglers of the previous range; plus the next chunk's
+                    // stragglers of MY range in the overlap zone ...
+                    bool mine = o < cend ? !((o < S + kWvOverlap) & (h < loSlot)) : ((o < plen) & !lastChunk & (h < limSlot));
+                    // ... shadow zone and head zone: tuples of the previous range's last granule are simulated here as well
+                    // (it lists the ones that really leave it; k_wave_validate compares)
+                    const bool shadowTuple = (o < S + kWvOverlap) & (h - loSlot + kGranSlots < kGranSlots) & (loSlot != 0);
+                    // ... and a tuple of MY range that sits before the seam ("early arrival": a key a little ahead of its
+                    // neighbours) is mine to insert; the previous wavefront leaves it (its tail zone, below)
+                    if (o < S) mine = shadowTuple | ((o >= claimFrom) & (h >= loSlot)); else mine = mine | shadowTuple;
+                    // my tail zone: tuples of the next range are the next wavefront's
+                    if ((o >= tailFrom) & (o < cend) & (h >= limSlot)) mine = false;
+                    // a tuple of the chunk proper, past the head zone, that belongs below my range: nobody else will insert
+                    // it (the previous wavefront reads kWvOverlap positions past its end, no more)
+                    const bool below = okKey & (o >= S + kWvOverlap) & (o < cend) & (h < loSlot);
+                    raise(below, 8ull);
+                    mine = mine & !below;
+                    zb |= ((mine ? 1u : 0u) << j) | ((in ? 1u : 0u) << (8 + j));
+                }
+            }
+        }
         auto classify = [&](auto fullTag) {
             constexpr bool FULL = decltype(fullTag)::value;
 #pragma unroll
             for (int j = 0; j < kWvPer; ++j) {
                 const uint32_t o = tb + lane + 64 * j;
-                const bool in = FULL || (o < clen);                               // counted here
-                const bool okKey = (khi[j] == 0) & (klo[j] != 0);
+                bool in, mineHere;
+                if constexpr (COMPACT && !FULL) {
+                    in = ((zb >> (8 + j)) & 1u) != 0; mineHere = ((zb >> j) & 1u) != 0;
+                } else {
+                    in = FULL || ((o >= S) & (o < cend));                         // counted here
+                }
+                bool okKey = (khi[j] == 0) & (klo[j] != 0);
                 home[j] = home32<HTM>(klo[j], hshift, mask32);
-                // inserted here: my tuples, except head-zone stragglers of the previous range; plus the next chunk's
-                // stragglers of MY range in the overlap zone
-                const bool mineHere = FULL || (o < clen ? !((o < kWvOverlap) & (home[j] < loSlot))
-                                                        : ((o < plen) & !lastChunk & (home[j] < limSlot)));
+                if constexpr (!(COMPACT && !FULL)) {
+                    // inserted here: my tuples, except head-zone stragglers of the previous range; plus the next chunk's
+                    // stragglers of MY range in the overlap zone
+                    mineHere = FULL || (o < cend ? !((o < S + kWvOverlap) & (home[j] < loSlot))
+                                                 : ((o < plen) & !lastChunk & (home[j] < limSlot)));
+                }
+                if constexpr (COMPACT) {
+                    // the compact empty pattern cannot be a key: the classic build takes such an input. Its home slot is the
+                    // table's last one, so a full tile (whose highest home slot is already known, tmaxF) only looks when
+                    // that slot occurs at all -- one vector instruction per tuple saved in every other tile
+                    if (!FULL || tmaxF == mask32) ffSeen |= in & (klo[j] == 0xFFFFFFFFu);
+                }
                 const bool ok = mineHere & okKey;
                 inSum += in ? (unsigned long long)wv_pack(khi[j], klo[j]) : 0ull;
-                if constexpr (FULL) badTile += 64u - (uint32_t)__popcll(__ballot(okKey));     // scalar: no per-lane count
+                if constexpr (FULL) badTile += 64u - (uint32_t)__popcll(wv_ballot(okKey));     // scalar: no per-lane count
                 else bad += (in & !okKey) ? 1u : 0u;
                 if constexpr (CHECK) foreign += (in & is_foreign(klo[j], sc)) ? 1u : 0u;
                 live[j] = ok;
-                if constexpr (FULL && HJ_WV_ALLIN) {
+                if constexpr (FULL && COMPACT) {
+                    // the bounds of a full tile were taken at its top (forced rounds)
+                } else if constexpr (FULL && HJ_WV_ALLIN) {
                     // full tiles take the bounds over every tuple, valid or not: an invalid key (the build fails with
                     // HJ_ERR_KEY_RANGE anyway) can only make the ring move less, and every access stays guarded
                     myMin = home[j] < myMin ? home[j] : myMin;
@@ -506,13 +704,14 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
         };
         if (full) classify(std::true_type{}); else classify(std::false_type{});
         bad += lane == 0 ? badTile : 0u;
-        const uint32_t tmin = wave_umin(myMin);                       // kNone: the tile holds no valid tuple
+        uint32_t tmin, tmax = 0;                                      // tmin == kNone: the tile holds no valid tuple
+        if (COMPACT && full) { tmin = tminF; tmax = tmaxF; }          // taken from the keys at the end of the tile before
+        else { tmin = wave_umin(myMin); if (tmin != kNone) tmax = ~wave_umin(myMaxInv); }
         bool allIn = false;                                           // wave-uniform: every home slot of the tile lies in ring and range
         if (tmin != kNone) {
             // The ring moves only as far as it must for the tile's highest home slot (+ a probe walk) to fit, so it
             // keeps as much history as it can: retry entries carried over from the previous tile are still inside.
             // It never moves past the tile's lowest home slot (an outlier key is deferred, not the tile).
-            const uint32_t tmax = ~wave_umin(myMaxInv);
             const uint32_t top = (uint32_t)(((uint64_t)tmax + probeLen + 8u) >> kGranShift) + 1u;
             uint32_t target = top > kWvGran ? top - kWvGran : 0u;
             const uint32_t gmin = tmin >> kGranShift;
@@ -559,7 +758,7 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
             mlo = disp ? (uint32_t)oldv[j] : mlo; mhi = disp ? (uint32_t)(oldv[j] >> 32) : mhi;
             const uint32_t pos = fail ? ((home[j] + 1) & mask32) : home[j];
             const bool again = fail | (lv & !ow);                      // outside ring or range: the retry round defers it
-            const unsigned long long am = __ballot(again);
+            const unsigned long long am = wv_ballot(again);
             if (am) {
                 if (again) {
                     const uint32_t at = (qHead + qCount + lane_rank(am)) & (kWvQCap - 1);
@@ -569,9 +768,58 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
             }
         }
 #if HJ_WV_CARRY
+        if constexpr (COMPACT) {
+            // Forced rounds. A queued entry whose slot the ring is about to leave behind would have to be deferred, and
+            // there is no deferred phase: it gets its rounds now, at the end of the tile, where nothing of the tile is
+            // in registers any more and the one retry loop of this place serves (fewer than 64 entries wait then: one
+            // lane each). How far the ring will move is known from the NEXT tile's keys, which the prefetch has already
+            // brought: a full tile's bounds go over every tuple, valid or not (rule of the ring above), and stay in two
+            // scalar registers for its classification; before a chunk's first and last tiles everything queued simply
+            // finishes. The first tile (shadow zone + head zone) ends the shadow phase the same way: once the queue is
+            // empty the shadow granule is dropped (it is never written), so that from here on a tuple that belongs below
+            // my range cannot land in it unnoticed -- it falls out of the ring and raises the flag.
+            const uint32_t tbN = tb + kWvTile;
+            uint32_t tslot = 0xFFFFFFFFu;
+            const bool endShadow = shadowOn;
+            if ((tbN + kWvTile <= (cend < tailFrom ? cend : tailFrom)) & (tbN >= S + kWvOverlap)) {
+                uint32_t mn = kNone, mxInv = kNone;
+#pragma unroll
+                for (int j = 0; j < kWvPer; ++j) {
+                    const uint32_t h = home32<HTM>((uint32_t)nxt[p][j], hshift, mask32);
+                    mn = h < mn ? h : mn; mxInv = ~h < mxInv ? ~h : mxInv;
+                }
+                tminF = wave_umin(mn); tmaxF = ~wave_umin(mxInv);
+                const uint32_t top = (uint32_t)(((uint64_t)tmaxF + probeLen + 8u) >> kGranShift) + 1u;
+                uint32_t target = top > kWvGran ? top - kWvGran : 0u;
+                const uint32_t gmin = tminF >> kGranShift;
+                target = target < gmin ? target : gmin;
+                target = target < limG ? target : limG;
+                if (!endShadow) tslot = target > winLoG ? target << kGranShift : 0u;
+            }
+            for (;;) {
+                bool need = qCount >= kWvRoundAt;
+                if (!need && qCount && tslot) {
+                    const uint32_t qp = myQPos[(qHead + lane) & (kWvQCap - 1)];
+                    need = wv_ballot((lane < qCount) & (qp < tslot)) != 0;
+#ifdef HJ_WV_STATS
+                    forcedRounds += need ? 1u : 0u;
+#endif
+                }
+                if (!need) break;
+                retry_round();
+            }
+            if (endShadow) {
+                shadowOn = false;
+                while (winLoG < loG) {
+                    reinterpret_cast<ulonglong2*>(win + ((winLoG & (kWvGran - 1)) << kGranShift))[lane] = make_ulonglong2(kEmpty, kEmpty);
+                    ++winLoG;
+                }
+            }
+        } else {
         while (qCount >= kWvRoundAt) retry_round();
         // an entry may wait for company for one tile, not longer (the ring moves on): no round during this tile -> one now
         if (qCount && rounds == roundsAtTileStart) retry_round();
+        }
 #else
         if (qCount) drain();                                           // before the ring may move on
 #endif
@@ -588,14 +836,26 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
         if (lastChunk) ctr->ownHiEx = (unsigned long long)winLoG << kGranShift;
         dcounts[c] = dCount;
         if constexpr (HTM) ccounts[c] = cCount;
+        if constexpr (COMPACT) pcounts[c] = pCount;
+    }
+    if constexpr (COMPACT) {
+        raise(ffSeen, 4ull);
+        dCount = 0;                              // crossers are not deferred tuples: the next wavefront has inserted them
     }
 
 #ifdef HJ_WV_CLOCKS
     if (lane == 0 && c < 65536) g_wvClk[2 * c + 1] = (uint32_t)wall_clock64();
 #endif
+#if HJ_WV_PRIO
+    __builtin_amdgcn_s_setprio(0);               // the rotation's priority is not carried into the counter atomics
+#endif
     // counters: one atomic per wavefront
     unsigned long long c0 = drops, c3 = bad | ((unsigned long long)foreign << 32);
+#ifdef HJ_WV_STATS
+    const unsigned long long c4 = (unsigned long long)rounds | ((unsigned long long)forcedRounds << 32);
+#else
     const unsigned long long c4 = dCount;
+#endif
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         c0 += __shfl_down(c0, off, 64);
@@ -663,7 +923,7 @@ k_wave_deferred(const DeferredEntry* __restrict__ queue, const uint32_t* __restr
             if constexpr (HTM) {
                 // the slice's conflict list is appended to by four wavefronts now: one atomic per wavefront reserves the places
                 // (ccounts[c] holds what k_build_wave recorded; the list's order is free, the chain phase sorts by index)
-                const unsigned long long cm = __ballot(dropped);
+                const unsigned long long cm = wv_ballot(dropped);
                 if (cm) {
                     uint32_t base = 0;
                     if (lane == (uint32_t)__ffsll((long long)cm) - 1u) base = atomicAdd(&ccounts[c], (uint32_t)__popcll(cm));
@@ -729,11 +989,91 @@ k_wave_fill_edges(uint64_t* __restrict__ table, const Counters* __restrict__ ctr
     if (blockIdx.x == 0 && threadIdx.x < kTableSlack) table[tableSize + threadIdx.x] = kEmpty;
 }
 
+
+// ---- compact table: the check and the decision (see k_build_wave<COMPACT>) ----------------------------------------
+// Seam c (between chunks c-1 and c): the tuples that left chunk c-1's range at its upper end must be exactly the ones
+// chunk c let in from its shadow granule. One thread per seam; the lists hold a handful of entries.
+__global__ void __launch_bounds__(kBlock)
+k_wave_validate(const DeferredEntry* __restrict__ queue, const uint32_t* __restrict__ dcounts, const uint32_t* __restrict__ pcounts,
+                uint32_t nChunks, uint32_t sliceLen, Counters* __restrict__ ctr, Gate gate)
+{
+    if (gate_closed(gate)) return;
+    if (*reinterpret_cast<volatile unsigned long long*>(&ctr->compactFail)) return;    // counts of skipped chunks are not defined
+    const uint32_t c = blockIdx.x * kBlock + threadIdx.x + 1;
+    if (c >= nChunks) return;
+    const uint32_t nOut = dcounts[c - 1], nIn = pcounts[c];
+    bool ok = nOut == nIn && nIn <= kWvPredCap;
+    if (ok && nIn) {
+        const DeferredEntry* out = queue + (uint64_t)(c - 1) * sliceLen;
+        const uint64_t* in = reinterpret_cast<const uint64_t*>(queue + (uint64_t)(c + 1) * sliceLen) - kWvPredCap;
+        for (uint32_t i = 0; i < nOut && ok; ++i) {
+            const uint64_t v = out[i].packed;
+            bool found = false;
+            for (uint32_t k = 0; k < nIn; ++k) found |= in[k] == v;
+            ok = found;                            // index words are unique: equal counts + every element found = equal sets
+        }
+    }
+    if (!ok) atomicOr(&ctr->compactFail, 16ull);
+}
+
+// One wavefront. All seams check out and nobody raised the flag: the table is in the compact format, its valid range is
+// what the wavefronts owned. Otherwise: as if the compact build had never run -- counters back to zero, and the variant
+// word set to the classic build that is enqueued behind this kernel, gated on it.
+__global__ void k_wave_decide(Counters* __restrict__ ctr, uint64_t tableSize, uint32_t fallbackVariant, Gate gate)
+{
+    if (blockIdx.x != 0 || threadIdx.x >= 64 || gate_closed(gate)) return;
+    static_assert(Counters::kShards == 64, "one shard per lane");
+    const bool fail = ctr->compactFail != 0;
+    if (fail) {
+        ctr->shard[threadIdx.x] = Counters::Shard{};
+        if (threadIdx.x == 0) {
+            ctr->conflicts = 0; ctr->conflictSum = 0; ctr->inputSum = 0; ctr->badKeys = 0; ctr->deferred = 0; ctr->foreign = 0;
+            ctr->usedLoInv = 0; ctr->usedHi1 = 0; ctr->ownLo = 0; ctr->ownHiEx = 0;
+            ctr->tableFormat = kFormatSlots8;
+            ctr->variant = fallbackVariant;
+        }
+        return;
+    }
+    if (threadIdx.x != 0) return;
+    unsigned long long lo = ctr->ownLo, hiEx = ctr->ownHiEx;
+    if (hiEx + 512 >= tableSize) { lo = 0; hiEx = tableSize; }
+    ctr->validLo = lo; ctr->validHiEx = hiEx;
+    ctr->tableFormat = kFormatKeys4;
+}
+
+// compact counterpart of k_wave_fill_edges: 4-byte empties over [validLo, ownLo) and [ownHiEx, validHiEx + 512) + slack
+__global__ void __launch_bounds__(kBlock)
+k_wave_fill_edges_keys(uint32_t* __restrict__ keys, const Counters* __restrict__ ctr, uint64_t tableSize, Gate gate)
+{
+    if (gate_closed(gate)) return;
+    const uint4 e = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    uint4* t4 = reinterpret_cast<uint4*>(keys);
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock, t0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    uint64_t hi = ctr->validHiEx + 512;
+    hi = hi < tableSize ? hi : tableSize;
+    const uint64_t a0 = ctr->validLo >> 2, a1 = ctr->ownLo >> 2;          // all bounds are multiples of 128 (granules) or 512
+    for (uint64_t v = a0 + t0; v < a1; v += stride) t4[v] = e;
+    const uint64_t b0 = ctr->ownHiEx >> 2, b1 = hi >> 2;
+    for (uint64_t v = b0 + t0; v < b1; v += stride) t4[v] = e;
+    if (blockIdx.x == 0 && threadIdx.x < kTableSlack) keys[tableSize + threadIdx.x] = 0xFFFFFFFFu;
+}
+
+__global__ void k_set_variant(Counters* __restrict__ ctr, uint32_t v)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctr->variant = v;
+}
+void launch_set_variant(Counters* ctr, uint32_t v, hipStream_t s) { hipLaunchKernelGGL(k_set_variant, dim3(1), dim3(64), 0, s, ctr, v); }
+
 // ---- host side ----------------------------------------------------------------------------------------------------
 size_t wave_lds_bytes() { return kWvLdsBytes; }
 bool wave_supported(uint64_t tableSize) { return tableSize >= (uint64_t)kWvWin; }
 uint32_t wave_max_chunks(int nCU) { return (uint32_t)HJ_WV_WAVES_PER_CU * (uint32_t)HJ_WV_MAX_ROUNDS * (uint32_t)nCU; }
-size_t wave_bounds_bytes(int nCU) { return (5 * (size_t)wave_max_chunks(nCU) + 4) * sizeof(uint32_t); }   // raw, bounds (+1), starts (+1), dcounts, ccounts
+size_t wave_bounds_bytes(int nCU) { return (6 * (size_t)wave_max_chunks(nCU) + 4) * sizeof(uint32_t); }   // raw, bounds (+1), starts (+1), dcounts, ccounts, pcounts
+bool wave_compact_supported(uint64_t tableSize, uint32_t probeLen)
+{
+    // the shadow granule must cover every slot a walk across the seam can start from
+    return wave_supported(tableSize) && probeLen >= 1 && probeLen <= 32;
+}
 static uint64_t wave_chunk_len(uint64_t n, int nCU)
 {
     // One chunk per resident wavefront is a single round of workgroups -- and the kernel then lasts as long as its
@@ -772,14 +1112,17 @@ size_t wave_conflict_bytes(uint64_t n, int nCU) { return wave_queue_bytes(n, nCU
 
 hipError_t launch_build_wave(const void* R, bool key32, uint64_t n, uint32_t hshift, uint64_t* table, uint64_t tableSize,
                              uint32_t probeLen, uint64_t idxBase, ShardCheck sc, int nCU, void* boundsBuf, void* queueBuf,
-                             Counters* ctr, Gate gate, int parts, hipEvent_t evPhaseA, hipStream_t s, uint64_t* htmConflicts)
+                             Counters* ctr, Gate gate, int parts, hipEvent_t evPhaseA, hipStream_t s, uint64_t* htmConflicts,
+                             int mode, uint32_t fallbackVariant)
 {
     const bool htm = htmConflicts != nullptr;
-    if (htm && (key32 || probeLen != 3 || sc.mask)) return hipErrorInvalidValue;
+    const bool compact = mode == kWaveCompact;
+    if (htm && (key32 || probeLen != 3 || sc.mask || compact)) return hipErrorInvalidValue;
     if (!key32 && hshift) return hipErrorInvalidValue;         // the kernel's tuple instances assume it
     const uint32_t maxChunks = wave_max_chunks(nCU);
     const uint64_t chunkLen = wave_chunk_len(n, nCU);
     static_assert(kWvTile * 4 > (int)(kWvLook + kWvOverlap), "a seam may move by less than the shortest chunk");
+    static_assert(kWvShadow + kWvOverlap == (uint32_t)kWvTile, "shadow zone + head zone = the first tile of a compact chunk");
     const uint32_t sliceLen = (uint32_t)wave_slice_len(chunkLen);
     const uint32_t nChunks = (uint32_t)((n + chunkLen - 1) / chunkLen);
     uint32_t* const raw = static_cast<uint32_t*>(boundsBuf);
@@ -787,26 +1130,46 @@ hipError_t launch_build_wave(const void* R, bool key32, uint64_t n, uint32_t hsh
     uint32_t* const starts = bounds + maxChunks + 1;          // nChunks + 1 entries
     uint32_t* const dcounts = starts + maxChunks + 1;
     uint32_t* const ccounts = dcounts + maxChunks;            // == wave_conflict_layout(...).counts
+    uint32_t* const pcounts = ccounts + maxChunks;
     const uint32_t numGran = (uint32_t)(tableSize >> kGranShift);
+    // workgroups a device of nCU compute units holds at once (the rotation of issue priorities goes by it)
+    const uint32_t residentWG = (uint32_t)HJ_WV_WAVES_PER_CU * (uint32_t)(nCU > 0 ? nCU : 256) / (uint32_t)kWvWaves;
     hipError_t e;
     const dim3 gRaw((nChunks + 1 + kBlock / 64 - 1) / (kBlock / 64)), gMain((nChunks + kWvWaves - 1) / kWvWaves);
-    if (parts & 1) {
-    if (htm) hipLaunchKernelGGL((k_wave_seams<false, true>), gRaw, dim3(kBlock), 0, s, R, n, (uint32_t)chunkLen, nChunks, tableSize - 1, hshift, starts, raw, gate);
-    else if (key32) hipLaunchKernelGGL((k_wave_seams<true, false>), gRaw, dim3(kBlock), 0, s, R, n, (uint32_t)chunkLen, nChunks, tableSize - 1, hshift, starts, raw, gate);
-    else hipLaunchKernelGGL((k_wave_seams<false, false>), gRaw, dim3(kBlock), 0, s, R, n, (uint32_t)chunkLen, nChunks, tableSize - 1, hshift, starts, raw, gate);
-    hipLaunchKernelGGL(k_wave_bounds_scan, dim3(1), dim3(kBlock), 0, s, raw, nChunks, numGran, bounds, gate);
-#define HJ_WV_LAUNCH(K32, CHK, HTM)                                                                                  \
-    hipLaunchKernelGGL((k_build_wave<K32, CHK, HTM>), gMain, dim3(kWvThreads), kWvLdsBytes, s, R, n, sliceLen,      \
-                       nChunks, starts, bounds, table, tableSize - 1, hshift, probeLen, idxBase, sc,                         \
-                       static_cast<DeferredEntry*>(queueBuf), dcounts, ctr, gate, htmConflicts, ccounts)
-    if (htm) HJ_WV_LAUNCH(false, false, true);
-    else if (sc.mask) { if (key32) HJ_WV_LAUNCH(true, true, false); else HJ_WV_LAUNCH(false, true, false); }
-    else { if (key32) HJ_WV_LAUNCH(true, false, false); else HJ_WV_LAUNCH(false, false, false); }
-#undef HJ_WV_LAUNCH
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    if (evPhaseA && (e = hipEventRecord(evPhaseA, s)) != hipSuccess) return e;
+    if (parts & kWavePre) {
+        if (htm) hipLaunchKernelGGL((k_wave_seams<false, true>), gRaw, dim3(kBlock), 0, s, R, n, (uint32_t)chunkLen, nChunks, tableSize - 1, hshift, starts, raw, gate);
+        else if (key32) hipLaunchKernelGGL((k_wave_seams<true, false>), gRaw, dim3(kBlock), 0, s, R, n, (uint32_t)chunkLen, nChunks, tableSize - 1, hshift, starts, raw, gate);
+        else hipLaunchKernelGGL((k_wave_seams<false, false>), gRaw, dim3(kBlock), 0, s, R, n, (uint32_t)chunkLen, nChunks, tableSize - 1, hshift, starts, raw, gate);
+        hipLaunchKernelGGL(k_wave_bounds_scan, dim3((nChunks + kBlock - 1) / kBlock), dim3(kBlock), 0, s, raw, nChunks, numGran, bounds, gate);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    if (!(parts & 2)) return hipSuccess;
+    if (parts & kWaveMain) {
+#define HJ_WV_LAUNCH(K32, CHK, HTM, CMP)                                                                             \
+    hipLaunchKernelGGL((k_build_wave<K32, CHK, HTM, CMP>), gMain, dim3(kWvThreads), kWvLdsBytes, s, R, n, sliceLen, \
+                       nChunks, starts, bounds, table, tableSize - 1, hshift, probeLen, idxBase, sc,                         \
+                       static_cast<DeferredEntry*>(queueBuf), dcounts, ctr, gate, htmConflicts, ccounts, residentWG, pcounts)
+        if (htm) HJ_WV_LAUNCH(false, false, true, false);
+        else if (compact) {
+            if (sc.mask) { if (key32) HJ_WV_LAUNCH(true, true, false, true); else HJ_WV_LAUNCH(false, true, false, true); }
+            else { if (key32) HJ_WV_LAUNCH(true, false, false, true); else HJ_WV_LAUNCH(false, false, false, true); }
+        }
+        else if (sc.mask) { if (key32) HJ_WV_LAUNCH(true, true, false, false); else HJ_WV_LAUNCH(false, true, false, false); }
+        else { if (key32) HJ_WV_LAUNCH(true, false, false, false); else HJ_WV_LAUNCH(false, false, false, false); }
+#undef HJ_WV_LAUNCH
+        if (compact) {
+            // the seams check out or the classic build takes over (Counters::variant := fallbackVariant)
+            hipLaunchKernelGGL(k_wave_validate, dim3((nChunks + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+                               static_cast<const DeferredEntry*>(queueBuf), dcounts, pcounts, nChunks, sliceLen, ctr, gate);
+            hipLaunchKernelGGL(k_wave_decide, dim3(1), dim3(64), 0, s, ctr, tableSize, fallbackVariant, gate);
+        }
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if (evPhaseA && (e = hipEventRecord(evPhaseA, s)) != hipSuccess) return e;
+    }
+    if (!(parts & kWaveTail)) return hipSuccess;
+    if (compact) {
+        hipLaunchKernelGGL(k_wave_fill_edges_keys, dim3(512), dim3(kBlock), 0, s, reinterpret_cast<uint32_t*>(table), ctr, tableSize, gate);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_wave_finalize_range, dim3(1), dim3(64), 0, s, ctr, tableSize, gate);
     hipLaunchKernelGGL(k_wave_fill_edges, dim3(2048), dim3(kBlock), 0, s, table, ctr, tableSize, gate);
     const dim3 gDef(nChunks);                                  // one workgroup per slice

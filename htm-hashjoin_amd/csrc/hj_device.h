@@ -86,6 +86,13 @@ struct Counters {
     // PRJ, histogram-free partitioning (hj_prj.hip): set to 1 by the scatter kernel that finds a fragment too small;
     // the rest of that path then returns at once and the exact (histogram) path, gated on this word, runs instead
     unsigned long long prjFallback;
+    // Open-addressing table formats (k_build_wave<COMPACT>, hj_build_wave.hip). tableFormat says what the table buffer
+    // holds after a build: kFormatSlots8 = one 8-byte slot (index << 32 | key) per table slot, all ones = empty (every
+    // build but the compact one); kFormatKeys4 = one 4-byte KEY per table slot, 0xFFFFFFFF = empty (the index words only
+    // order the inserts; the compact build settles every order inside its LDS rings and never writes them out). k_probe,
+    // k_table_sums and hj_export_table read the word. compactFail: raised by the compact build when it meets something
+    // only the classic builds can handle; k_wave_decide then resets the counters and hands over to the classic build.
+    unsigned long long tableFormat, compactFail;
     // The sums every wavefront contributes to at the END of a kernel (above: conflicts, conflictSum, inputSum, matches,
     // badKeys, prjMatches, prjChecksum, deferred, foreign, and the two maxima usedLoInv / usedHi1) are collected in 64
     // shards, each on a 128-byte line of its own, picked by wavefront number. Thousands of wavefronts finish together, and
@@ -123,8 +130,15 @@ inline void fold_counter_shards(Counters* h)
 // Device-side choice between the build variants (hj_build_dev must stay asynchronous: no host read-back). The host
 // enqueues the kernels of EVERY candidate variant; each looks at the word the pre-round wrote and returns at once
 // unless it is the chosen one. word = nullptr: no gate (the variant was fixed on the host).
-struct Gate { const unsigned long long* word; unsigned long long want; };
-__device__ inline bool gate_closed(const Gate& g) { return g.word != nullptr && *g.word != g.want; }
+// alt: a second value that opens the gate (the pre-pass shared by the compact and the classic ring build)
+struct Gate { const unsigned long long* word; unsigned long long want; unsigned long long alt = ~0ull; };
+__device__ inline bool gate_closed(const Gate& g)
+{
+    if (g.word == nullptr) return false;
+    const unsigned long long v = *g.word;
+    return v != g.want && v != g.alt;
+}
+constexpr unsigned long long kFormatSlots8 = 0, kFormatKeys4 = 1;
 
 // A tuple that left its LDS window (variants 2 and 3): the slot it had reached and (index << 32 | key)
 struct DeferredEntry { uint64_t pos; uint64_t packed; };
@@ -135,6 +149,7 @@ struct DeferredEntry { uint64_t pos; uint64_t packed; };
 void launch_fill_empty(uint64_t* table, uint64_t nSlots, Gate gate, hipStream_t s);
 void launch_build_atomic_min(const void* R, bool key32, uint64_t n, uint64_t* table, uint64_t tableSize, uint32_t hshift,
                              uint32_t probeLen, uint64_t idxBase, ShardCheck sc, Counters* ctr, Gate gate, hipStream_t s);
+// the probe and the checksums read Counters::tableFormat on the device: either table format, one launch
 void launch_probe(const void* S, bool key32, uint64_t n, const uint64_t* table, uint64_t tableSize, uint32_t hshift,
                   uint32_t probeLen, ShardCheck sc, Counters* ctr, hipStream_t s);
 void launch_table_sums(const uint64_t* table, uint64_t tableSize, uint64_t halfSlots, Counters* ctr, hipStream_t s);
@@ -159,11 +174,12 @@ hipError_t launch_sample_locality(const void* R, bool key32, uint64_t n, uint64_
                                   unsigned int* fitCount, hipStream_t s);
 // the pre-round's decision on the device: ctr->variant = 3 / 2 / 1 by the same thresholds the host applies
 // (sample_thresholds below); canOwn / canWave: which variants have their buffers
-void launch_pick_variant(const unsigned int* fitCount, bool canOwn, bool canWave, Counters* ctr, hipStream_t s);
+void launch_pick_variant(const unsigned int* fitCount, bool canOwn, bool canWave, Counters* ctr, hipStream_t s, bool canCompact = false);
 // variant worth taking for a sample (outside variant 2's window, tuples seen, outside variant 3's ring)
-__host__ __device__ inline uint32_t variant_for_sample(uint64_t outOwn, uint64_t seen, uint64_t outWave, bool canOwn, bool canWave)
+__host__ __device__ inline uint32_t variant_for_sample(uint64_t outOwn, uint64_t seen, uint64_t outWave, bool canOwn, bool canWave,
+                                                      bool canCompact = false)
 {
-    if (canWave && outWave * 128 <= seen) return 3;
+    if (canWave && outWave * 128 <= seen) return canCompact ? 4 : 3;
     if (canOwn && outOwn * 12 <= seen) return 2;
     return 1;
 }
@@ -190,10 +206,19 @@ size_t wave_bounds_bytes(int nCU);
 size_t wave_queue_bytes(uint64_t n, int nCU);   // deferred queue: one slice per chunk
 // bounds pre-pass -> k_build_wave -> valid range + edge fill -> phase B. queueBuf: own_queue_bytes(n), used as one
 // slice per chunk (a wavefront's deferred tuples go to ITS slice: no atomics in the kernel).
+// parts: kWavePre = the seam / bounds pre-pass, kWaveMain = the build kernel (then evPhaseA), kWaveTail = valid range,
+// edge fill and the deferred phase. mode kWaveCompact: the compact build (4-byte table, no deferred phase) -- its main
+// part is k_build_wave<COMPACT> + the seam check + k_wave_decide, which on failure resets the counters and sets
+// Counters::variant = fallbackVariant so that the classic build enqueued behind it (gated on that word) redoes the table;
+// its tail is the edge fill alone. The pre-pass is the same for both modes (gate it with alt).
+constexpr int kWavePre = 1, kWaveMain = 2, kWaveTail = 4, kWaveAll = 7;
+constexpr int kWaveClassic = 0, kWaveCompact = 1;
 hipError_t launch_build_wave(const void* R, bool key32, uint64_t n, uint32_t hshift, uint64_t* table, uint64_t tableSize,
                              uint32_t probeLen, uint64_t idxBase, ShardCheck sc, int nCU, void* boundsBuf, void* queueBuf,
                              Counters* ctr, Gate gate, int parts, hipEvent_t evPhaseA, hipStream_t s,
-                             uint64_t* htmConflicts = nullptr);
+                             uint64_t* htmConflicts = nullptr, int mode = kWaveClassic, uint32_t fallbackVariant = 3);
+bool wave_compact_supported(uint64_t tableSize, uint32_t probeLen);
+void launch_set_variant(Counters* ctr, uint32_t v, hipStream_t s);
 // htmConflicts != nullptr: the bucketised table of --algo htm (home_slot_htm, probeLen must be 3, tuples only); every
 // tuple that runs out of budget is appended as (index << 32 | key) to its chunk's slice of htmConflicts (slices and
 // their counts as wave_conflict_layout describes)

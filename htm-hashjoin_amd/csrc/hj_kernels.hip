@@ -201,6 +201,34 @@ __device__ __forceinline__ uint32_t probe_one(uint64_t sk, const uint64_t* __res
     return m;
 }
 
+// The same walk over a compact table (Counters::tableFormat == kFormatKeys4): one 4-byte key per slot, 0xFFFFFFFF = empty
+__device__ __forceinline__ uint32_t probe_one_keys(uint64_t sk, const uint32_t* __restrict__ keys,
+                                                   uint64_t mask, uint32_t hshift, uint32_t probeLen,
+                                                   uint64_t validLo, uint64_t validHiEx)
+{
+    const uint32_t key = (uint32_t)sk;
+    const uint64_t home = home_slot(key, hshift, mask);
+    if ((sk >> 32) != 0 || home < validLo || home >= validHiEx) return 0;
+    const uint32_t* p = keys + home;
+    constexpr uint32_t e = 0xFFFFFFFFu;
+    uint32_t m = 0;
+    if (probeLen == 4) {
+        const uint32_t a = p[0], b = p[1], c = p[2], d = p[3];    // slack slots make this safe
+        const bool ea = a != e, eb = ea && b != e, ec = eb && c != e, ed = ec && d != e;
+        m += (ea && a == key);
+        m += (eb && b == key);
+        m += (ec && c == key);
+        m += (ed && d == key);
+    } else {
+        for (uint32_t j = 0; j < probeLen; ++j) {
+            const uint32_t v = p[j];
+            if (v == e) break;
+            m += (v == key);
+        }
+    }
+    return m;
+}
+
 // Window of one S element, loaded unconditionally (two 16-byte loads; the slack slots past the table end make
 // that safe): an element that cannot match reads the window at `dummy` instead and counts nothing. No branch sits
 // between the loads of a lane's elements, so all of them are in flight together.
@@ -218,6 +246,27 @@ __device__ __forceinline__ Window load_window(uint32_t key, const uint64_t* __re
     return w;
 }
 
+struct WindowK { uint32_t a, b, c, d; uint32_t key; bool ok; };
+__device__ __forceinline__ WindowK load_window_keys(uint32_t key, const uint32_t* __restrict__ keys, uint64_t mask,
+                                                    uint32_t hshift, uint64_t validLo, uint64_t validHiEx, uint64_t dummy)
+{
+    WindowK w;
+    w.key = key;
+    const uint64_t home = home_slot(key, hshift, mask);
+    w.ok = home >= validLo && home < validHiEx;
+    const uint32_t* p = keys + (w.ok ? home : dummy);
+    w.a = p[0]; w.b = p[1]; w.c = p[2]; w.d = p[3];
+    return w;
+}
+__device__ __forceinline__ uint32_t count_window_keys(const WindowK& w)
+{
+    constexpr uint32_t e = 0xFFFFFFFFu;
+    const bool ea = w.a != e, eb = ea && w.b != e, ec = eb && w.c != e, ed = ec && w.d != e;
+    const uint32_t m = (uint32_t)(ea && w.a == w.key) + (uint32_t)(eb && w.b == w.key) + (uint32_t)(ec && w.c == w.key) +
+                       (uint32_t)(ed && w.d == w.key);
+    return w.ok ? m : 0u;
+}
+
 __device__ __forceinline__ uint32_t count_window(const Window& w)
 {
     // NoCCHashBuild.hpp:70-79 with probeLength 4: stop at the first empty slot, count slots equal to the key
@@ -232,12 +281,13 @@ __device__ __forceinline__ uint32_t count_window(const Window& w)
 // read-stream rate (6.1-6.35 TB/s), and batching its loads made it slower. Keys: four windows per lane,
 // which one after the other meant five dependent round trips per iteration (4.2 TB/s); their eight loads are
 // issued together.
-template <bool KEY32>
-__global__ void __launch_bounds__(kBlock)
-k_probe(const void* __restrict__ Sv, uint64_t n, const uint64_t* __restrict__ table, uint64_t mask,
-        uint32_t hshift, uint32_t probeLen, ShardCheck sc, Counters* __restrict__ ctr)
+template <bool KEY32, bool COMPACT>
+__device__ __forceinline__ void probe_body(const void* __restrict__ Sv, uint64_t n, const uint64_t* __restrict__ table, uint64_t mask,
+                                           uint32_t hshift, uint32_t probeLen, ShardCheck sc, Counters* __restrict__ ctr)
 {
     using Elem = typename std::conditional<KEY32, uint32_t, uint64_t>::type;
+    const uint32_t* const keys = reinterpret_cast<const uint32_t*>(table);      // COMPACT: the table buffer holds 4-byte keys
+    (void)keys;
     constexpr uint64_t EPV = 16 / sizeof(Elem);
     unsigned long long matches = 0;
     uint32_t foreign = 0;                                          // shard check (off: always 0)
@@ -255,7 +305,20 @@ k_probe(const void* __restrict__ Sv, uint64_t n, const uint64_t* __restrict__ ta
         const uint4 t = make_uint4(tt.x, tt.y, tt.z, tt.w);
         if constexpr (KEY32) {
             foreign += (uint32_t)is_foreign(t.x, sc) + (uint32_t)is_foreign(t.y, sc) + (uint32_t)is_foreign(t.z, sc) + (uint32_t)is_foreign(t.w, sc);
-            if (probeLen == 4) {
+            if constexpr (COMPACT) {
+                if (probeLen == 4) {
+                    const WindowK w0 = load_window_keys(t.x, keys, mask, hshift, validLo, validHiEx, dummy);
+                    const WindowK w1 = load_window_keys(t.y, keys, mask, hshift, validLo, validHiEx, dummy);
+                    const WindowK w2 = load_window_keys(t.z, keys, mask, hshift, validLo, validHiEx, dummy);
+                    const WindowK w3 = load_window_keys(t.w, keys, mask, hshift, validLo, validHiEx, dummy);
+                    matches += count_window_keys(w0) + count_window_keys(w1) + count_window_keys(w2) + count_window_keys(w3);
+                } else {
+                    matches += probe_one_keys(t.x, keys, mask, hshift, probeLen, validLo, validHiEx);
+                    matches += probe_one_keys(t.y, keys, mask, hshift, probeLen, validLo, validHiEx);
+                    matches += probe_one_keys(t.z, keys, mask, hshift, probeLen, validLo, validHiEx);
+                    matches += probe_one_keys(t.w, keys, mask, hshift, probeLen, validLo, validHiEx);
+                }
+            } else if (probeLen == 4) {
                 const Window w0 = load_window(t.x, table, mask, hshift, validLo, validHiEx, dummy);
                 const Window w1 = load_window(t.y, table, mask, hshift, validLo, validHiEx, dummy);
                 const Window w2 = load_window(t.z, table, mask, hshift, validLo, validHiEx, dummy);
@@ -269,16 +332,36 @@ k_probe(const void* __restrict__ Sv, uint64_t n, const uint64_t* __restrict__ ta
             }
         } else {
             foreign += (uint32_t)is_foreign(t.x, sc) + (uint32_t)is_foreign(t.z, sc);
-            matches += probe_one(((uint64_t)t.y << 32) | t.x, table, mask, hshift, probeLen, validLo, validHiEx);
-            matches += probe_one(((uint64_t)t.w << 32) | t.z, table, mask, hshift, probeLen, validLo, validHiEx);
+            if constexpr (COMPACT) {
+                matches += probe_one_keys(((uint64_t)t.y << 32) | t.x, keys, mask, hshift, probeLen, validLo, validHiEx);
+                matches += probe_one_keys(((uint64_t)t.w << 32) | t.z, keys, mask, hshift, probeLen, validLo, validHiEx);
+            } else {
+                matches += probe_one(((uint64_t)t.y << 32) | t.x, table, mask, hshift, probeLen, validLo, validHiEx);
+                matches += probe_one(((uint64_t)t.w << 32) | t.z, table, mask, hshift, probeLen, validLo, validHiEx);
+            }
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        for (uint64_t i = 0; i < head; ++i) { matches += probe_one(S[i], table, mask, hshift, probeLen, validLo, validHiEx); foreign += is_foreign((uint32_t)S[i], sc); }
-        for (uint64_t i = head + nv * EPV; i < n; ++i) { matches += probe_one(S[i], table, mask, hshift, probeLen, validLo, validHiEx); foreign += is_foreign((uint32_t)S[i], sc); }
+        auto one = [&](uint64_t sk) {
+            return COMPACT ? probe_one_keys(sk, keys, mask, hshift, probeLen, validLo, validHiEx)
+                           : probe_one(sk, table, mask, hshift, probeLen, validLo, validHiEx);
+        };
+        for (uint64_t i = 0; i < head; ++i) { matches += one(S[i]); foreign += is_foreign((uint32_t)S[i], sc); }
+        for (uint64_t i = head + nv * EPV; i < n; ++i) { matches += one(S[i]); foreign += is_foreign((uint32_t)S[i], sc); }
     }
     flush_counter(&counter_shard(ctr)->matches, matches);
     flush_counter(&counter_shard(ctr)->foreign, foreign);
+}
+
+// One launch for either table format: the build decides the format on the device (Counters::tableFormat), the probe is
+// enqueued behind it without a host round trip and branches once, wave-uniformly.
+template <bool KEY32>
+__global__ void __launch_bounds__(kBlock)
+k_probe(const void* __restrict__ Sv, uint64_t n, const uint64_t* __restrict__ table, uint64_t mask,
+        uint32_t hshift, uint32_t probeLen, ShardCheck sc, Counters* __restrict__ ctr)
+{
+    if (ctr->tableFormat == kFormatKeys4) probe_body<KEY32, true>(Sv, n, table, mask, hshift, probeLen, sc, ctr);
+    else probe_body<KEY32, false>(Sv, n, table, mask, hshift, probeLen, sc, ctr);
 }
 
 void launch_probe(const void* S, bool key32, uint64_t n, const uint64_t* table, uint64_t tableSize, uint32_t hshift,
@@ -304,6 +387,19 @@ k_table_sums(const uint64_t* __restrict__ table, uint64_t tableSize, uint64_t ha
     const uint64_t lo = ctr->validLo;
     uint64_t hi = ctr->validHiEx + 512;
     if (hi > tableSize) hi = tableSize;
+    if (ctr->tableFormat == kFormatKeys4) {               // compact table: 4-byte keys, two per 8 bytes
+        const uint2* k2 = reinterpret_cast<const uint2*>(table);
+        for (uint64_t v = (lo >> 1) + (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < (hi >> 1); v += (uint64_t)gridDim.x * kBlock) {
+            const uint2 t = k2[v];
+            const uint64_t a = t.x == 0xFFFFFFFFu ? 0 : t.x, b = t.y == 0xFFFFFFFFu ? 0 : t.y;
+            full += a + b;
+            if (2 * v < halfSlots) half += a;
+            if (2 * v + 1 < halfSlots) half += b;
+        }
+        flush_counter(&ctr->tableSumHalf, half);
+        flush_counter(&ctr->tableSumFull, full);
+        return;
+    }
     const uint64_t nv = hi >> 1;
     for (uint64_t v = (lo >> 1) + (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (uint64_t)gridDim.x * kBlock) {
         const ulonglong2 t = t2[v];

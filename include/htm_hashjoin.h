@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HJ_ABI_VERSION 3
+#define HJ_ABI_VERSION 4
 
 typedef enum {
     HJ_OK                  = 0,
@@ -84,7 +84,12 @@ typedef struct {
                                  up to a shuffle window of ~2000 positions);
                                  3 = wavefront-private LDS rings over statically owned slot
                                  ranges (tight locality, the reference's default
-                                 --shuffleRange 16); all give the same table            */
+                                 --shuffleRange 16);
+                                 4 = the same rings writing a COMPACT table (4-byte keys: the
+                                 index words that order the inserts never leave the LDS; no
+                                 deferred phase; if the input needs one, 3 redoes the table,
+                                 decided on the device) -- what 0 picks where 3 would do;
+                                 all give the same table (hj_export_table) and counters    */
     uint32_t prjMode;         /* PRJ: 0 = partition large relations without histograms (fragments
                                  sized for uniform low key bits, checked; the exact passes of
                                  parallel_radix_join.c:586-626 run instead when one overflows);
@@ -109,7 +114,7 @@ typedef struct {
                                  (parallel_radix_join.c:256) when radixBits=14    */
     uint64_t prjPartitions;   /* PRJ: number of final partitions                  */
     uint32_t radixBits;       /* PRJ: bits actually used                          */
-    uint32_t buildVariant;    /* kernel actually used                             */
+    uint32_t buildVariant;    /* kernel actually used (4 only if the compact build held) */
     /* device time of the last call of each phase, from HIP events on the
      * context's stream, in microseconds */
     double clear_us, build_us, probe_us, partition_us, join_us, total_us;
@@ -134,6 +139,11 @@ typedef struct {
     uint64_t htmBuckets;          /* numBuckets                                           */
     uint64_t htmOverflowBuckets;  /* overflow buckets linked into chains (:231-279)       */
     uint64_t htmOverflowSum;      /* sum of the tuples they hold (== conflictSum)         */
+    uint64_t compactFallback;     /* open addressing: 0 = the compact ring build (buildVariant 4) held or was not
+                                     tried; else why it handed over to the classic build -- bit 0: a tuple outside
+                                     ring and range (no locality there), bit 1: more than 64 walks across one seam,
+                                     bit 2: key 0xFFFFFFFF, bit 3: a tuple far below its chunk's range, bit 4: a
+                                     seam's two sides disagree (the shadow granule missed a tuple)                */
 } hj_result;
 
 typedef struct hj_ctx hj_ctx;

@@ -40,7 +40,7 @@ def test_struct_layouts_match_header():
 
 
 def test_abi_version_and_strerror():
-    assert hj.lib.hj_abi_version() == 3
+    assert hj.lib.hj_abi_version() == 4
     assert b"no gfx950" in hj.lib.hj_strerror(_lib.HJ_ERR_NO_DEVICE)
     assert hj.lib.hj_strerror(0) == b"ok"
 
