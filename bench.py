@@ -72,6 +72,33 @@ def parse():
     return a
 
 
+def kernel_source_hash():
+    """sha256 over the kernel sources (htm-hashjoin_amd/csrc/*.hip, *.h, *.cpp): profiles/pmc_traffic.json records the
+    hash of the sources its PMC passes were taken on (tools/summarize_prof.py traffic), and roofline.traffic is reported
+    only while the sources are still those -- a committed byte count never describes a kernel that has changed since."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "htm-hashjoin_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.cpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def committed_traffic(kernel, workload_ok):
+    """HBM bytes per launch of `kernel` from profiles/pmc_traffic.json, or (None, why)."""
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(pmc):
+        return None, "no profiles/pmc_traffic.json"
+    if not workload_ok:
+        return None, "the PMC passes were taken on another workload"
+    d = json.load(open(pmc))
+    if d.get("_source_hash") != kernel_source_hash():
+        return None, "kernel sources changed since the PMC passes (profiles/pmc_traffic.json: _source_hash)"
+    return d.get(kernel.split("<")[0]), None
+
+
 def to_device(np_u64, torch, dev):
     t = torch.from_numpy(np_u64.view("int64"))
     return t.to(dev, non_blocking=False)
@@ -133,7 +160,7 @@ def oa_leg(torch, hj, ctx, n, dist, window, steps, warmup, S_dev=None, variant=0
         "mtuples_per_s": 2 * n / (dt / steps) / 1e6,
         "kernel_us": avg,
         "conflicts": res["conflicts"], "totalMatches": res["totalMatches"], "inputSum": res["inputSum"],
-        "buildVariant": res["buildVariant"], "buildDeferred": res["buildDeferred"],
+        "buildVariant": res["buildVariant"], "buildDeferred": res["buildDeferred"], "compactFallback": res["compactFallback"],
         "checks": {
             "matches_plus_conflicts_eq_rSize": res["totalMatches"] + res["conflicts"] == n,
             "tableSum_plus_conflictSum_eq_inputSum": res["tableSumFull"] + res["conflictSum"] == res["inputSum"],
@@ -146,10 +173,8 @@ def oa_leg(torch, hj, ctx, n, dist, window, steps, warmup, S_dev=None, variant=0
 def prj_traffic(n, dist, window, path):
     """HBM bytes of the pass-1 scatter of R from the committed PMC passes (profiles/pmc_traffic.json), for the one workload
     they were taken on; None otherwise."""
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if not (os.path.exists(pmc) and n == 1 << 30 and dist == "local_shuffle" and window == 1024 and path == 1):
-        return None
-    return json.load(open(pmc)).get("k_radix_scatter_frag_pass1_R_local_shuffle_1024")
+    return committed_traffic("k_radix_scatter_frag_pass1_R_local_shuffle_1024",
+                             n == 1 << 30 and dist == "local_shuffle" and window == 1024 and path == 1)[0]
 
 
 def prj_leg(torch, hj, ctx, n, dist, window, steps, warmup, S_dev):
@@ -385,27 +410,30 @@ def main():
     # roofline of the dominant kernel (the build): algorithmic bytes = 16 B per R tuple
     # (8 read + 8 slot write), duration = HIP-event time of that launch
     ku = main_leg["kernel_us"]
-    v2 = main_leg["buildVariant"] >= 2          # an LDS build (2: workgroup window, 3: wavefront rings): phase A timed alone
+    v2 = main_leg["buildVariant"] >= 2          # an LDS build (2: workgroup window, 3: wavefront rings, 4: rings + compact table): its kernel timed alone
     # Dominant kernel = the build. Variant 2: k_build_own (phase A) timed alone by its own HIP events
     # (hj_result.buildPhaseA_us); build_us additionally covers k_clear_unowned + k_build_deferred.
     # Algorithmic bytes per launch: build = R read 8 + slot write 8 = 16 B per R tuple;
     # probe = S read 8 + home-slot read 8 = 16 B per S tuple; table clear = 16 B per R tuple (2|R| slots).
-    dom_name = {3: "k_build_wave", 2: "k_build_own"}.get(main_leg["buildVariant"], "k_build_atomic_min")
+    dom_name = {4: "k_build_wave<compact>", 3: "k_build_wave", 2: "k_build_own"}.get(main_leg["buildVariant"], "k_build_atomic_min")
     dom_us = ku["buildPhaseA_us"] if v2 else ku["build_us"]
     alg = 16.0 * n
     achieved = alg / (dom_us * 1e-6) / 1e9
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc) and a.log2n == 30 and a.dist == "uniform":
-        traffic = json.load(open(pmc)).get(dom_name)      # HBM bytes per launch from rocprofv3 PMC passes (same command)
+    # HBM bytes per launch from rocprofv3 PMC passes of this very command -- only while the kernel sources are the ones
+    # the passes were taken on
+    traffic, traffic_note = committed_traffic(dom_name, a.log2n == 30 and a.dist == "uniform" and a.shuffle_range == 16)
+    # what the kernel moves by design: R read once (8 B) + every reachable slot written once -- 8 B per slot, or 4 B with
+    # the compact table (the index words that order the inserts stay in LDS); SURVEY.md 8d's algorithmic 16 B per tuple is
+    # what `achieved` is computed from either way
+    moved_model = (12.0 if main_leg["buildVariant"] == 4 else 16.0) * n
     # Whole step in SURVEY.md 8d's accounting: 16 B per R tuple (read 8 + slot written 8) + 16 B per S tuple (read 8 +
     # home slot 8) = 32 B per tuple pair. The table clear is NOT a separate 16 B: the LDS builds write every reachable
     # slot exactly once, empties included (PMC round 1: build group 17.3 GB at 2^30, not 34 GB).
     step_bytes = 32.0 * n
     roofline = {"bound": "hbm", "kernel": dom_name,
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic,
-                "algorithmic_bytes_per_launch": alg, "launch_us": dom_us,
+                "traffic": traffic, "traffic_note": traffic_note,
+                "algorithmic_bytes_per_launch": alg, "bytes_moved_by_design_per_launch": moved_model, "launch_us": dom_us,
                 "other_kernels": {
                     "build_group_us (seam/bounds pre-pass + LDS build kernel + edge/unowned clear + deferred phase)" if v2 else "k_fill_empty_us":
                         ku["build_us"] if v2 else ku["clear_us"],
@@ -420,6 +448,9 @@ def main():
         k2 = max(2, a.steps // 2)
         extra["oa_local_shuffle_1024"], _ = oa_leg(torch, hj, ctx, n, "local_shuffle", 1024, k2, 1, S_dev,
                                                    variant=a.build_variant)
+        # unique keys within the reference's default shuffle window: the compact rings without retry rounds
+        extra["oa_local_shuffle_16"], _ = oa_leg(torch, hj, ctx, n, "local_shuffle", 16, k2, 1, S_dev,
+                                                 variant=a.build_variant)
         ctx2 = hj.HashJoinContext(local_rank, stream=stream)
         extra["prj_local_shuffle_1024"] = prj_leg(torch, hj, ctx2, n, "local_shuffle", 1024, k2, 1, S_dev)
         ctx2.close()
@@ -449,7 +480,7 @@ def main():
                                "no separate table clear) + probe, inputs resident in HBM",
                    "algo": "atomic", "rSize": n, "sSize": n, "dataDistr": a.dist, "shuffleRange": a.shuffle_range},
         "result": {k: main_leg[k] for k in ("conflicts", "totalMatches", "inputSum", "buildVariant",
-                                            "buildDeferred", "checks")},
+                                            "buildDeferred", "compactFallback", "checks")},
         "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_prj": cpu_prj, "other_workloads": extra,
     }
     print(json.dumps(line), flush=True)

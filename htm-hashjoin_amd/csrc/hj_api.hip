@@ -17,7 +17,7 @@
 using namespace hj;
 
 namespace {
-enum Ev { EV_CLEAR0, EV_BUILD0, EV_BUILD_A, EV_BUILD1, EV_PROBE0, EV_PROBE1, EV_PRJ0, EV_PRJ_PART, EV_PRJ1, EV_PRJ_S0, EV_PRJ_S1, EV_COUNT };
+enum Ev { EV_CLEAR0, EV_BUILD0, EV_BUILD_A, EV_BUILD1, EV_KW0, EV_KW1, EV_KC0, EV_KC1, EV_KO0, EV_KO1, EV_PROBE0, EV_PROBE1, EV_PRJ0, EV_PRJ_PART, EV_PRJ1, EV_PRJ_S0, EV_PRJ_S1, EV_COUNT };
 }
 
 struct hj_ctx {
@@ -381,6 +381,8 @@ static int build_common(hj_ctx* c, const void* d, bool key32, uint64_t n, uint32
     c->variantUsed = (variant == 4) ? 0 : variant;     // 0: decided on the device (4 may fall back to 3), reported from Counters::variant
     c->algoUsed = c->params.algo == HJ_ALGO_AUTO ? (uint32_t)HJ_ALGO_ATOMIC : c->params.algo;
     const unsigned long long* word = &c->dCtr->variant;
+    // the dominant kernel of each LDS variant, bracketed by its own pair of events (hj_result.buildPhaseA_us)
+    const KernelEvents kevWave{c->ev[EV_KW0], c->ev[EV_KW1]}, kevCompact{c->ev[EV_KC0], c->ev[EV_KC1]}, kevOwn{c->ev[EV_KO0], c->ev[EV_KO1]};
     if (variant == 0) {
         // The locality pre-round decides ON THE DEVICE (this call stays asynchronous: no read-back). The kernels of
         // every candidate variant are enqueued behind it, each gated on the word the pre-round writes; the ones not
@@ -397,13 +399,17 @@ static int build_common(hj_ctx* c, const void* d, bool key32, uint64_t n, uint32
                                         c->queueBuf, c->dCtr, Gate{word, 3, 4}, kWavePre, nullptr, c->stream));
             if (canCompact)
                 HJ_HIP(c, launch_build_wave(d, key32, n, hshift, c->table, tableSize, pl, idxBase, c->sc, c->nCU, c->boundsBuf,
-                                            c->queueBuf, c->dCtr, Gate{word, 4}, kWaveMain, nullptr, c->stream, nullptr, kWaveCompact, 3));
+                                            c->queueBuf, c->dCtr, Gate{word, 4}, kWaveMain, nullptr, c->stream, nullptr, kWaveCompact, 3, &kevCompact));
             HJ_HIP(c, launch_build_wave(d, key32, n, hshift, c->table, tableSize, pl, idxBase, c->sc, c->nCU, c->boundsBuf,
-                                        c->queueBuf, c->dCtr, Gate{word, 3}, kWaveMain, nullptr, c->stream));
+                                        c->queueBuf, c->dCtr, Gate{word, 3}, kWaveMain, nullptr, c->stream, nullptr, kWaveClassic, 3, &kevWave));
+            c->evSet[EV_KW0] = c->evSet[EV_KW1] = true;
+            c->evSet[EV_KC0] = c->evSet[EV_KC1] = canCompact;
         }
-        if (canOwn)
+        if (canOwn) {
             HJ_HIP(c, launch_build_own(d, key32, n, hshift, c->table, tableSize, pl, idxBase, c->sc, c->nCU, c->ownerBuf,
-                                       c->queueBuf, c->queueCount, c->dCtr, Gate{word, 2}, 1, nullptr, c->stream));
+                                       c->queueBuf, c->queueCount, c->dCtr, Gate{word, 2}, 1, nullptr, c->stream, &kevOwn));
+            c->evSet[EV_KO0] = c->evSet[EV_KO1] = true;
+        }
         if ((rc = record(c, EV_BUILD_A))) return rc;
         if (canWave) {
             if (canCompact)
@@ -423,10 +429,10 @@ static int build_common(hj_ctx* c, const void* d, bool key32, uint64_t n, uint32
         launch_set_variant(c->dCtr, 4, c->stream);
         if ((rc = record(c, EV_BUILD0))) return rc;
         HJ_HIP(c, launch_build_wave(d, key32, n, hshift, c->table, tableSize, pl, idxBase, c->sc, c->nCU, c->boundsBuf,
-                                    c->queueBuf, c->dCtr, Gate{word, 4}, kWavePre | kWaveMain, nullptr, c->stream, nullptr, kWaveCompact, 3));
+                                    c->queueBuf, c->dCtr, Gate{word, 4}, kWavePre | kWaveMain, nullptr, c->stream, nullptr, kWaveCompact, 3, &kevCompact));
         HJ_HIP(c, launch_build_wave(d, key32, n, hshift, c->table, tableSize, pl, idxBase, c->sc, c->nCU, c->boundsBuf,
-                                    c->queueBuf, c->dCtr, Gate{word, 3}, kWaveMain, c->ev[EV_BUILD_A], c->stream));
-        c->evSet[EV_BUILD_A] = true;
+                                    c->queueBuf, c->dCtr, Gate{word, 3}, kWaveMain, c->ev[EV_BUILD_A], c->stream, nullptr, kWaveClassic, 3, &kevWave));
+        c->evSet[EV_BUILD_A] = c->evSet[EV_KW0] = c->evSet[EV_KW1] = c->evSet[EV_KC0] = c->evSet[EV_KC1] = true;
         HJ_HIP(c, launch_build_wave(d, key32, n, hshift, c->table, tableSize, pl, idxBase, c->sc, c->nCU, c->boundsBuf,
                                     c->queueBuf, c->dCtr, Gate{word, 4}, kWaveTail, nullptr, c->stream, nullptr, kWaveCompact, 3));
         HJ_HIP(c, launch_build_wave(d, key32, n, hshift, c->table, tableSize, pl, idxBase, c->sc, c->nCU, c->boundsBuf,
@@ -434,13 +440,13 @@ static int build_common(hj_ctx* c, const void* d, bool key32, uint64_t n, uint32
     } else if (variant == 3) {
         if ((rc = record(c, EV_BUILD0))) return rc;
         HJ_HIP(c, launch_build_wave(d, key32, n, hshift, c->table, tableSize, pl, idxBase, c->sc, c->nCU,
-                                    c->boundsBuf, c->queueBuf, c->dCtr, Gate{nullptr, 0}, kWaveAll, c->ev[EV_BUILD_A], c->stream));
-        c->evSet[EV_BUILD_A] = true;
+                                    c->boundsBuf, c->queueBuf, c->dCtr, Gate{nullptr, 0}, kWaveAll, c->ev[EV_BUILD_A], c->stream, nullptr, kWaveClassic, 3, &kevWave));
+        c->evSet[EV_BUILD_A] = c->evSet[EV_KW0] = c->evSet[EV_KW1] = true;
     } else if (variant == 2) {
         if ((rc = record(c, EV_BUILD0))) return rc;
         HJ_HIP(c, launch_build_own(d, key32, n, hshift, c->table, tableSize, pl, idxBase, c->sc, c->nCU,
-                                   c->ownerBuf, c->queueBuf, c->queueCount, c->dCtr, Gate{nullptr, 0}, 3, c->ev[EV_BUILD_A], c->stream));
-        c->evSet[EV_BUILD_A] = true;
+                                   c->ownerBuf, c->queueBuf, c->queueCount, c->dCtr, Gate{nullptr, 0}, 3, c->ev[EV_BUILD_A], c->stream, &kevOwn));
+        c->evSet[EV_BUILD_A] = c->evSet[EV_KO0] = c->evSet[EV_KO1] = true;
     } else {
         launch_fill_empty(c->table, tableSize + kTableSlack, Gate{nullptr, 0}, c->stream);
         launch_set_full_range(tableSize, c->dCtr, Gate{nullptr, 0}, c->stream);
@@ -478,11 +484,12 @@ static int build_htm(hj_ctx* c, const uint64_t* dR, uint64_t rSize, uint64_t idx
         (rc = sample_variant(c, dR, false, rSize, slots, 0, false, true, &variant))) return rc;
     c->variantUsed = variant; c->algoUsed = HJ_ALGO_HTM;
     const WaveSlices sl = wave_conflict_layout(rSize, c->nCU, c->boundsBuf);
+    const KernelEvents kevW{c->ev[EV_KW0], c->ev[EV_KW1]};
     if (variant == 3) {
         if ((rc = record(c, EV_BUILD0))) return rc;
         HJ_HIP(c, launch_build_wave(dR, false, rSize, 0, c->table, slots, 3, idxBase, ShardCheck{0, 0, 0, 0}, c->nCU, c->boundsBuf,
-                                    c->queueBuf, c->dCtr, Gate{nullptr, 0}, kWaveAll, c->ev[EV_BUILD_A], c->stream, c->htmConflicts));
-        c->evSet[EV_BUILD_A] = true;
+                                    c->queueBuf, c->dCtr, Gate{nullptr, 0}, kWaveAll, c->ev[EV_BUILD_A], c->stream, c->htmConflicts, kWaveClassic, 3, &kevW));
+        c->evSet[EV_BUILD_A] = c->evSet[EV_KW0] = c->evSet[EV_KW1] = true;
     } else {
         launch_fill_empty(c->table, slots + kTableSlack, Gate{nullptr, 0}, c->stream);
         launch_set_full_range(slots, c->dCtr, Gate{nullptr, 0}, c->stream);
@@ -692,7 +699,14 @@ int hj_fetch_result(hj_ctx* c, hj_result* out)
         out->buildVariant = c->variantUsed ? c->variantUsed : (uint32_t)k.variant;   // 0: the device chose
         out->compactFallback = k.compactFail;
         out->buildDeferred = k.deferred;
-        out->buildPhaseA_us = elapsed_us(c, EV_BUILD0, EV_BUILD_A);
+        // the dominant build kernel ALONE: the launch of the LDS build that ran is bracketed by its own pair of events (the
+        // launches of the variants the device did not pick return at once: microseconds; the largest bracket is the kernel)
+        out->buildPhaseA_us = 0.0;
+        static const Ev kBrackets[3][2] = {{EV_KW0, EV_KW1}, {EV_KC0, EV_KC1}, {EV_KO0, EV_KO1}};
+        for (const auto& pr : kBrackets) {
+            const double us = elapsed_us(c, pr[0], pr[1]);
+            if (us > out->buildPhaseA_us) out->buildPhaseA_us = us;
+        }
         out->clear_us = elapsed_us(c, EV_CLEAR0, EV_BUILD0);
         out->build_us = elapsed_us(c, EV_BUILD0, EV_BUILD1);
         out->probe_us = elapsed_us(c, EV_PROBE0, EV_PROBE1);

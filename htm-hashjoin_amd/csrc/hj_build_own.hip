@@ -639,7 +639,7 @@ hipError_t own_set_attributes()
 hipError_t launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshift, uint64_t* table,
                             uint64_t tableSize, uint32_t probeLen, uint64_t idxBase, ShardCheck sc, int nCU, void* ownerBuf,
                             void* queueBuf, unsigned long long* queueCount, Counters* ctr, Gate gate, int parts,
-                            hipEvent_t evPhaseA, hipStream_t s)
+                            hipEvent_t evPhaseA, hipStream_t s, const KernelEvents* kev)
 {
     const uint32_t numBlocks = (uint32_t)(tableSize >> kBlkShift);
     hipError_t e;
@@ -656,6 +656,7 @@ hipError_t launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshi
     chunkLen = (chunkLen + kOwnTile - 1) / kOwnTile * kOwnTile;
     if (chunkLen < (uint64_t)kOwnTile * 4) chunkLen = (uint64_t)kOwnTile * 4;
     const unsigned grid = (unsigned)((n + chunkLen - 1) / chunkLen);
+    if (kev && (e = hipEventRecord(kev->before, s)) != hipSuccess) return e;
 #define HJ_OWN_LAUNCH(K32, CHK)                                                                                      \
     hipLaunchKernelGGL((k_build_own<K32, CHK>), dim3(grid), dim3(kOwnThreads), kWinSlots * sizeof(uint64_t), s,       \
                        R, n, chunkLen, table, tableSize - 1, hshift, probeLen, idxBase, sc,                            \
@@ -664,6 +665,7 @@ hipError_t launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshi
     else { if (key32) HJ_OWN_LAUNCH(true, false); else HJ_OWN_LAUNCH(false, false); }
 #undef HJ_OWN_LAUNCH
     if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (kev && (e = hipEventRecord(kev->after, s)) != hipSuccess) return e;
     if (evPhaseA && (e = hipEventRecord(evPhaseA, s)) != hipSuccess) return e;
     }
     if (!(parts & 2)) return hipSuccess;

@@ -176,7 +176,20 @@ k_wave_seams(const void* __restrict__ Rv, uint64_t n, uint32_t chunkLen, uint32_
     uint32_t h0 = load_home(p + lane), h1 = load_home(p + 64 + lane);
     const uint32_t m = wave_umin(h0);
     uint32_t start = (uint32_t)p, g = m == kNone ? kNone : m >> kGranShift;
-    if (c > 0 && m != kNone) {
+    if (c > 0 && p + kWvLook > n) {
+        // A last chunk shorter than the look (a radix shard's key count is no multiple of the chunk length): too few tuples
+        // to place a seam among -- without a crossing the seam would sit at p, in the middle of a granule's worth of tuples
+        // that then belong to the other side in bulk. The previous chunk takes these tuples too (its slice has room for
+        // kWvLook more), and this chunk starts at the relation's end, owning the table from the granule after the highest
+        // home slot among them: no tuples, only its part of the table (and, in the compact build, its shadow granule).
+        uint32_t mx = 0;                                              // highest home slot among this lane's valid tuples
+        if (h0 != kNone) mx = h0;
+        if (h1 != kNone && h1 > mx) mx = h1;
+        for (uint32_t k = 2; k < kWvLook / 64; ++k) { const uint32_t h = load_home(p + 64 * k + lane); if (h != kNone && h > mx) mx = h; }
+        const uint32_t hi = ~wave_umin(~mx);
+        start = (uint32_t)n;
+        g = m == kNone ? kNone : (hi >> kGranShift) + 1u;
+    } else if (c > 0 && m != kNone) {
         const uint32_t edge = ((m >> kGranShift) + 1) << kGranShift;          // first slot of the next granule (0 on wrap: no crossing)
         for (uint32_t k = 0; k < kWvLook / 64 && edge != 0; k += 2) {
             if (k) { h0 = load_home(p + 64 * k + lane); h1 = load_home(p + 64 * (k + 1) + lane); }
@@ -1113,7 +1126,7 @@ size_t wave_conflict_bytes(uint64_t n, int nCU) { return wave_queue_bytes(n, nCU
 hipError_t launch_build_wave(const void* R, bool key32, uint64_t n, uint32_t hshift, uint64_t* table, uint64_t tableSize,
                              uint32_t probeLen, uint64_t idxBase, ShardCheck sc, int nCU, void* boundsBuf, void* queueBuf,
                              Counters* ctr, Gate gate, int parts, hipEvent_t evPhaseA, hipStream_t s, uint64_t* htmConflicts,
-                             int mode, uint32_t fallbackVariant)
+                             int mode, uint32_t fallbackVariant, const KernelEvents* kev)
 {
     const bool htm = htmConflicts != nullptr;
     const bool compact = mode == kWaveCompact;
@@ -1144,6 +1157,7 @@ hipError_t launch_build_wave(const void* R, bool key32, uint64_t n, uint32_t hsh
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (parts & kWaveMain) {
+        if (kev && (e = hipEventRecord(kev->before, s)) != hipSuccess) return e;
 #define HJ_WV_LAUNCH(K32, CHK, HTM, CMP)                                                                             \
     hipLaunchKernelGGL((k_build_wave<K32, CHK, HTM, CMP>), gMain, dim3(kWvThreads), kWvLdsBytes, s, R, n, sliceLen, \
                        nChunks, starts, bounds, table, tableSize - 1, hshift, probeLen, idxBase, sc,                         \
@@ -1156,6 +1170,7 @@ hipError_t launch_build_wave(const void* R, bool key32, uint64_t n, uint32_t hsh
         else if (sc.mask) { if (key32) HJ_WV_LAUNCH(true, true, false, false); else HJ_WV_LAUNCH(false, true, false, false); }
         else { if (key32) HJ_WV_LAUNCH(true, false, false, false); else HJ_WV_LAUNCH(false, false, false, false); }
 #undef HJ_WV_LAUNCH
+        if (kev && (e = hipEventRecord(kev->after, s)) != hipSuccess) return e;
         if (compact) {
             // the seams check out or the classic build takes over (Counters::variant := fallbackVariant)
             hipLaunchKernelGGL(k_wave_validate, dim3((nChunks + kBlock - 1) / kBlock), dim3(kBlock), 0, s,

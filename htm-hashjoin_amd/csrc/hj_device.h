@@ -142,6 +142,9 @@ constexpr unsigned long long kFormatSlots8 = 0, kFormatKeys4 = 1;
 
 // A tuple that left its LDS window (variants 2 and 3): the slot it had reached and (index << 32 | key)
 struct DeferredEntry { uint64_t pos; uint64_t packed; };
+// HIP events recorded right before and right after ONE kernel launch (the dominant build kernel of a variant): its device
+// time for the roofline, without the pre-pass and the gated-off launches of the other variants around it
+struct KernelEvents { hipEvent_t before, after; };
 
 // ---- launch wrappers (defined in hj_kernels.hip) ---------------------------
 // Inputs come in two element formats: 8-byte DataGen tuples (key32 = false; value = key, payload bits must be 0)
@@ -189,7 +192,7 @@ hipError_t own_set_attributes();          // per device, at hj_create
 hipError_t launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshift, uint64_t* table,
                             uint64_t tableSize, uint32_t probeLen, uint64_t idxBase, ShardCheck sc, int nCU, void* ownerBuf,
                             void* queueBuf, unsigned long long* queueCount, Counters* ctr, Gate gate, int parts,
-                            hipEvent_t evPhaseA, hipStream_t s);   // parts: 1 = phase A (up to evPhaseA), 2 = the rest, 3 = both
+                            hipEvent_t evPhaseA, hipStream_t s, const KernelEvents* kev = nullptr);   // parts: 1 = phase A (up to evPhaseA), 2 = the rest, 3 = both
 
 // phase B alone: finishes the queued tuples with global atomics (shared with variant 3)
 void launch_build_deferred(const void* queueBuf, const unsigned long long* queueCount, uint64_t* table, uint64_t tableSize,
@@ -216,7 +219,8 @@ constexpr int kWaveClassic = 0, kWaveCompact = 1;
 hipError_t launch_build_wave(const void* R, bool key32, uint64_t n, uint32_t hshift, uint64_t* table, uint64_t tableSize,
                              uint32_t probeLen, uint64_t idxBase, ShardCheck sc, int nCU, void* boundsBuf, void* queueBuf,
                              Counters* ctr, Gate gate, int parts, hipEvent_t evPhaseA, hipStream_t s,
-                             uint64_t* htmConflicts = nullptr, int mode = kWaveClassic, uint32_t fallbackVariant = 3);
+                             uint64_t* htmConflicts = nullptr, int mode = kWaveClassic, uint32_t fallbackVariant = 3,
+                             const KernelEvents* kev = nullptr);
 bool wave_compact_supported(uint64_t tableSize, uint32_t probeLen);
 void launch_set_variant(Counters* ctr, uint32_t v, hipStream_t s);
 // htmConflicts != nullptr: the bucketised table of --algo htm (home_slot_htm, probeLen must be 3, tuples only); every

@@ -25,6 +25,9 @@
 
 #include "../../include/htm_hashjoin.h"
 
+#include <sched.h>
+
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -92,6 +95,28 @@ double now_us()
     return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// CPUs this process may really use: its affinity mask, capped by the cgroup's CPU quota. hardware_concurrency() reports
+// the host's CPUs -- a GPU box hands a container 16 of 64+, and the sweep's CPU legs said "cpu_threads: 64" while running
+// on 16 (round-2 VERDICT, weak #8). Same rule as bench.py's effective_cpus().
+static unsigned effective_cpus()
+{
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) n = (unsigned)CPU_COUNT(&set);
+    long long quota = -1, period = 0;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                 // cgroup v2: "<quota|max> <period>"
+        char q[32] = {0};
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    } else if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
+        if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+        fclose(g);
+        if (FILE* h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 0; fclose(h); }
+    }
+    if (quota > 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+    return std::max(1u, n);
+}
+
 // ---- the reference's CPU loops on host threads ------------------------------
 struct cpu_result { uint64_t conflicts = 0, matches = 0, inputSum = 0, outputSum = 0; double us = 0; int threads = 0; };
 
@@ -114,7 +139,7 @@ cpu_result cpu_build_probe(bool useCas, const uint64_t* R, uint64_t rSize, const
     std::vector<std::atomic<uint64_t>> output(tableSize + 4);
     for (auto& s : output) s.store(0, std::memory_order_relaxed);
     std::vector<uint64_t> conf(numPartitions, 0), confSum(numPartitions, 0), match(numPartitions, 0);
-    int nthreads = (int)std::min<unsigned>(numPartitions, std::max(1u, std::thread::hardware_concurrency()));
+    int nthreads = (int)std::min<unsigned>(numPartitions, effective_cpus());
     res.threads = nthreads;
     const double t0 = now_us();
     for_chunks(numPartitions, nthreads, [&](uint32_t c) {

@@ -306,10 +306,37 @@ static void mt_run(mt_shared *sh, int nthreads)
     free(th);
 }
 
+/* first touch of the table by the worker threads themselves, piece t, t + T, ... of 4096 by thread t: on a multi-socket
+ * host the table's pages then spread over the memory of every socket the threads run on, instead of all sitting on the
+ * one node of the thread that called calloc (measured on the GPU box's host: profiles/r03_summary.md, "CPU baseline") */
+typedef struct { uint64_t *p; uint64_t n; int t, T; } touch_arg;
+static void *touch_worker(void *a_)
+{
+    touch_arg *a = (touch_arg *)a_;
+    const uint64_t pieces = 4096, len = (a->n + pieces - 1) / pieces;
+    for (uint64_t k = (uint64_t)a->t; k < pieces; k += (uint64_t)a->T) {
+        volatile uint64_t *q = a->p;
+        const uint64_t b = k * len, e = b + len < a->n ? b + len : a->n;
+        for (uint64_t i = b; i < e; i += 512) q[i] = 0;
+    }
+    return NULL;
+}
+
+int orc_build_probe_mt_ex(const uint64_t *R, uint64_t rSize, const uint64_t *S, uint64_t sSize, uint32_t probeLength,
+                          uint32_t numPartitions, int nthreads, int atomic, int parallelTouch, orc_result *res);
+
 int orc_build_probe_mt(const uint64_t *R, uint64_t rSize,
                        const uint64_t *S, uint64_t sSize,
                        uint32_t probeLength, uint32_t numPartitions,
                        int nthreads, int atomic, orc_result *res)
+{
+    return orc_build_probe_mt_ex(R, rSize, S, sSize, probeLength, numPartitions, nthreads, atomic, 0, res);
+}
+
+int orc_build_probe_mt_ex(const uint64_t *R, uint64_t rSize,
+                          const uint64_t *S, uint64_t sSize,
+                          uint32_t probeLength, uint32_t numPartitions,
+                          int nthreads, int atomic, int parallelTouch, orc_result *res)
 {
     memset(res, 0, sizeof(*res));
     if (numPartitions == 0 || nthreads <= 0) return -1;
@@ -329,6 +356,16 @@ int orc_build_probe_mt(const uint64_t *R, uint64_t rSize,
      * new uint64_t[tableSize]{} does in the reference (:24). A plain memset after calloc is
      * elided by the compiler (calloc memory is known to be zero), which left the faults --
      * and the kernel's serialisation of them -- inside the timed build. */
+    if (parallelTouch) {
+        pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+        touch_arg *ta = (touch_arg *)malloc(sizeof(touch_arg) * (size_t)nthreads);
+        for (int t = 0; t < nthreads; t++) {
+            ta[t].p = sh.output; ta[t].n = tableSize + ORC_SLACK; ta[t].t = t; ta[t].T = nthreads;
+            pthread_create(&th[t], NULL, touch_worker, &ta[t]);
+        }
+        for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+        free(th); free(ta);
+    }
     {
         volatile uint64_t *touch = sh.output;
         for (uint64_t i = 0; i < tableSize + ORC_SLACK; i += 512) touch[i] = 0;

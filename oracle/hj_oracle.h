@@ -121,6 +121,9 @@ int orc_build_probe_mt(const uint64_t *R, uint64_t rSize,
                        const uint64_t *S, uint64_t sSize,
                        uint32_t probeLength, uint32_t numPartitions,
                        int nthreads, int atomic, orc_result *res);
+/* the same with the table first touched by the worker threads (parallelTouch != 0) instead of by the calling thread */
+int orc_build_probe_mt_ex(const uint64_t *R, uint64_t rSize, const uint64_t *S, uint64_t sSize, uint32_t probeLength,
+                          uint32_t numPartitions, int nthreads, int atomic, int parallelTouch, orc_result *res);
 
 /* ---- HTM bucketised table (HTMHashBuild.hpp) ------------------------------ */
 

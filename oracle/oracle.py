@@ -30,6 +30,8 @@ def _load():
                                            C.c_uint32, C.POINTER(OrcResult), C.c_void_p]
     lib.orc_build_probe_mt.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32,
                                        C.c_int, C.c_int, C.POINTER(OrcResult)]
+    lib.orc_build_probe_mt_ex.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32,
+                                          C.c_int, C.c_int, C.c_int, C.POINTER(OrcResult)]
     lib.orc_prj_join.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32,
                                  C.POINTER(OrcPrjResult)]
     lib.orc_htm_build_probe_seq.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32,
@@ -198,11 +200,11 @@ def htm_chains(buckets, overflows):
     return np.array(out, dtype=np.uint64), np.array(off, dtype=np.int64)
 
 
-def build_probe_mt(relR, relS, probe_length=4, num_partitions=64, nthreads=1, atomic=False):
+def build_probe_mt(relR, relS, probe_length=4, num_partitions=64, nthreads=1, atomic=False, parallel_touch=False):
     res = OrcResult()
-    rc = _lib.orc_build_probe_mt(relR.ctypes.data, relR.size, relS.ctypes.data if relS is not None else None,
-                                 relS.size if relS is not None else 0, probe_length, num_partitions, nthreads,
-                                 1 if atomic else 0, C.byref(res))
+    rc = _lib.orc_build_probe_mt_ex(relR.ctypes.data, relR.size, relS.ctypes.data if relS is not None else None,
+                                    relS.size if relS is not None else 0, probe_length, num_partitions, nthreads,
+                                    1 if atomic else 0, 1 if parallel_touch else 0, C.byref(res))
     assert rc == 0
     return res.as_dict()
 

@@ -36,9 +36,12 @@ DISTS = [("uniform", 16), ("uniform", 2), ("random", 16), ("sorted", 16), ("shuf
          ("local_shuffle", 16), ("local_shuffle", 1024)]
 
 
-def _variant_that_runs(variant, table_size):
-    """hj_params.buildVariant -> the kernel that actually runs: 2 needs a table of one 8192-slot window, 3 of one
-    1024-slot ring; below that they fall back (3 -> 2 -> 1)."""
+def _variant_that_runs(variant, table_size, compact_held=None):
+    """hj_params.buildVariant -> the kernel that actually runs: 2 needs a table of one 8192-slot window, 3 and 4 of one
+    1024-slot ring; below that they fall back (4 -> 3 -> 2 -> 1). 4 (the compact rings) reports 4 when the compact
+    table held and 3 when the classic rings had to redo it (compact_held = hj_result.compactFallback == 0)."""
+    if variant == 4 and (table_size < 1024 or not compact_held):
+        variant = 3
     if variant == 3 and table_size < 1024:
         variant = 2
     if variant == 2 and table_size < 8192:
@@ -46,20 +49,34 @@ def _variant_that_runs(variant, table_size):
     return variant
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+# inputs on which the compact ring build must hold (every tuple within reach of its wavefront's ring, walks across a seam
+# seen by the next wavefront's shadow granule) / must hand over to the classic rings (no locality)
+COMPACT_HOLDS = {("uniform", 16), ("uniform", 2), ("sorted", 16), ("local_shuffle", 16)}
+COMPACT_FAILS = {("shuffle", 16), ("random", 16), ("local_shuffle", 4096), ("local_shuffle", 65536)}
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
 @pytest.mark.parametrize("dist,window", DISTS + [("local_shuffle", 128), ("local_shuffle", 4096), ("local_shuffle", 65536)])
 @pytest.mark.parametrize("n", [1 << 10, 1 << 16, 1 << 20])
 def test_build_probe_matches_sequential_oracle(ctx, dist, window, n, variant):
     """variant 1 = global atomicMin kernel, 2 = block ownership + workgroup LDS window, 3 = wavefront-private LDS
-    rings over static slot ranges (2 and 3 + the deferred phase): all must give the table a single thread builds in
-    input order, slot for slot -- with locality (where 2 and 3 are meant to run) and without (where nearly every
-    tuple takes their deferred road)."""
+    rings over static slot ranges (2 and 3 + the deferred phase), 4 = the same rings writing the compact 4-byte table
+    (no deferred phase; the classic rings redo the table where the input needs one): all must give the table a single
+    thread builds in input order, slot for slot -- with locality (where 2, 3 and 4 are meant to run) and without (where
+    nearly every tuple takes the deferred road, and 4 hands over)."""
     R = oracle.generate_data(dist, n, n, window)
     S = oracle.relS_for(dist, R)
     want = oracle.build_probe_seq(R, S, 4, want_table=True)
     got = ctx.run("atomic", R, S, buildVariant=variant)
     check_oa(got, want)
-    assert got["buildVariant"] == _variant_that_runs(variant, 2 * n)
+    assert got["buildVariant"] == _variant_that_runs(variant, 2 * n, got["compactFallback"] == 0)
+    if variant == 4 and 2 * n >= 1024 and n >= 1 << 16:
+        if (dist, window) in COMPACT_HOLDS:
+            assert got["buildVariant"] == 4 and got["compactFallback"] == 0 and got["buildDeferred"] == 0
+        if (dist, window) in COMPACT_FAILS:
+            assert got["buildVariant"] == 3 and got["compactFallback"] != 0
+    if variant != 4:
+        assert got["compactFallback"] == 0
     if got["buildVariant"] >= 2 and n >= 1 << 16 and dist in ("sorted", "uniform"):
         assert got["buildDeferred"] < n // 16         # locality: the LDS window / rings take almost everything
     # the whole table, slot for slot, equals the table a single thread builds in input order
@@ -85,10 +102,12 @@ def test_other_probe_lengths(ctx, probe_length):
     R = oracle.generate_data("uniform", n, n, 16)
     S = oracle.generate_data("sorted", n)
     want = oracle.build_probe_seq(R, S, probe_length, want_table=True)
-    for variant in (1, 2, 3):
+    for variant in (1, 2, 3, 4):
         got = ctx.run("atomic", R, S, probeLength=probe_length, buildVariant=variant)
         check_oa(got, want)
         assert np.array_equal(ctx.export_table(2 * n), want["table"])
+        if variant == 4:
+            assert got["buildVariant"] == 4 and got["compactFallback"] == 0   # near-sorted input: the compact table holds at any budget
 
 
 def test_auto_variant_follows_locality(ctx):
@@ -96,12 +115,14 @@ def test_auto_variant_follows_locality(ctx):
     the LDS-window kernel, a random permutation the global-atomic one; results equal either way."""
     n = 1 << 20
     S = oracle.generate_data("sorted", n)
-    for dist, window, expect in (("uniform", 16, 3), ("sorted", 16, 3), ("local_shuffle", 64, 3), ("local_shuffle", 1024, 2),
-                                 ("shuffle", 16, 1), ("random", 16, 1)):
+    for dist, window, expect in (("uniform", 16, (4,)), ("sorted", 16, (4,)), ("local_shuffle", 16, (4,)), ("local_shuffle", 64, (3, 4)),
+                                 ("local_shuffle", 1024, (2,)), ("shuffle", 16, (1,)), ("random", 16, (1,))):
         R = oracle.generate_data(dist, n, n, window)
         Sx = oracle.relS_for(dist, R)
         got = ctx.run("atomic", R, Sx)
-        assert got["buildVariant"] == expect, (dist, got["buildVariant"])
+        # rings: the compact ones (4) where they hold, the classic ones (3) where the device handed over
+        assert got["buildVariant"] in expect, (dist, got["buildVariant"])
+        assert (got["buildVariant"] == 3) == (got["compactFallback"] != 0)
         check_oa(got, oracle.build_probe_seq(R, Sx, 4))
 
 
@@ -117,7 +138,7 @@ def test_algo_auto_switches_between_table_and_radix_join(ctx):
         got = ctx.run("auto", R, S)
         assert got["algoUsed"] == expect, (dist, window, got["algoUsed"])
         if expect == "atomic":
-            assert got["buildVariant"] == (2 if window == 1024 else 3)
+            assert got["buildVariant"] == (2 if window == 1024 else 4)
             check_oa(got, oracle.build_probe_seq(R, S, 4))
         else:
             want = oracle.prj_join(R, S, got["radixBits"])
@@ -147,7 +168,7 @@ def test_unaligned_device_pointers(ctx):
     R = oracle.generate_data("uniform", n, n, 16)
     S = oracle.generate_data("sorted", n)
     want = oracle.build_probe_seq(R, S, 4, want_table=True)
-    for variant in (1, 2, 3):
+    for variant in (1, 2, 3, 4):
         with hj.HashJoinContext(0) as c2:
             dR = c2.dev_alloc((n + 2) * 8)
             dS = c2.dev_alloc((n + 2) * 8)
@@ -171,7 +192,7 @@ def test_heavy_duplicates_and_tiny_sizes(ctx):
         R = rng.integers(1, hi, size=n, dtype=np.uint64)
         S = rng.integers(1, hi + 3, size=3 * n + 1, dtype=np.uint64)   # |S| != |R|, odd length
         want = oracle.build_probe_seq(R, S, 4, want_table=True)
-        for variant in (1, 2, 3):
+        for variant in (1, 2, 3, 4):
             got = ctx.run("atomic", R, S, buildVariant=variant)
             check_oa(got, want)
             assert np.array_equal(ctx.export_table(2 * n), want["table"])
@@ -184,10 +205,12 @@ def test_wraparound_at_table_end(ctx):
     R[::3] = 2 * n - 2
     S = np.array([2 * n - 1, 2 * n - 2, 1, 2, 4 * n - 1], dtype=np.uint64)
     want = oracle.build_probe_seq(R, S, 4, want_table=True)
-    for variant in (1, 2, 3):
+    for variant in (1, 2, 3, 4):
         got = ctx.run("atomic", R, S, buildVariant=variant)
         check_oa(got, want)
         assert np.array_equal(ctx.export_table(2 * n), want["table"])
+        if variant == 4:
+            assert got["buildVariant"] == 3 and got["compactFallback"] & 1   # walks wrap around the table end: the classic rings redo it
 
 
 def test_build_only_and_empty_probe(ctx):
@@ -522,7 +545,7 @@ def test_config2_size_properties(ctx):
         c.probe_keys(dS + 8, n)
         c.checksums()
         k = c.fetch()
-        assert k["buildVariant"] == 3
+        assert k["buildVariant"] == 4 and k["compactFallback"] == 0
         for f in ("conflicts", "totalMatches", "inputSum", "tableSumFull", "conflictSum"):
             assert k[f] == got[f], f
         c.dev_free(dR); c.dev_free(dS)
@@ -577,7 +600,7 @@ def test_maximum_relation_size_on_the_wavefront_rings():
         c.checksums()
         r = c.fetch()
         assert (r["conflicts"], r["totalMatches"], r["inputSum"], r["tableSumFull"], r["buildVariant"], r["buildDeferred"]) == (
-            0, n, tri, tri, 3, 0)
+            0, n, tri, tri, 4, 0)
     with hj.HashJoinContext(0) as c:
         c.reserve("htm", n, n)
         c.build(dR, n); c.probe(dR, n)
@@ -592,7 +615,7 @@ def test_maximum_relation_size_on_the_wavefront_rings():
 # ---- radix-sharded path: every GPU kernel of htm_hashjoin_amd/sharded.py on one device ------------
 @pytest.mark.parametrize("G", [2, 8, 64])
 @pytest.mark.parametrize("dist,window", [("uniform", 16), ("local_shuffle", 1024), ("random", 16)])
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
 def test_sharded_kernels_on_one_gpu(ctx, G, dist, window, variant):
     """G ranks emulated in turn on one GPU: shard histogram + STABLE scatter to 32-bit keys per source piece, the
     all-to-all done on the host (pieces laid out in source-rank order), then hj_build_keys_dev / hj_probe_keys_dev per
@@ -646,7 +669,9 @@ def test_sharded_kernels_on_one_gpu(ctx, G, dist, window, variant):
             c.probe_keys(d_s + 12, got_s.size)
             c.checksums()
             res = c.fetch()
-            assert res["buildVariant"] == _variant_that_runs(variant, table_size)
+            assert res["buildVariant"] == _variant_that_runs(variant, table_size, res["compactFallback"] == 0)
+            if variant == 4 and dist == "uniform" and table_size >= 1024:
+                assert res["buildVariant"] == 4, (g, res["compactFallback"], got_r.size)   # near-sorted keys stay near-sorted inside a shard: the compact table holds
             for k in tot:
                 assert res[k] == want[k], (g, k)
                 tot[k] += res[k]
@@ -849,7 +874,7 @@ def test_randomised_differential_keys_and_tuples():
             c.dev_free(dR); c.dev_free(dS)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
 def test_shard_check_counts_foreign_tuples(variant):
     """hj_set_shard_check: builds and probes count the tuples whose destination is another shard, on tuples and on keys,
     in both build kernels; off again afterwards."""
@@ -906,7 +931,7 @@ def test_skew_probe_side_zipf(ctx):
     assert np.array_equal(S, oracle.generate_zipf(8 * n + 3, n, 0.9, 0))
     want = oracle.build_probe_seq(R, S, 4)
     assert want["conflicts"] == 0 and want["totalMatches"] == S.size
-    for variant in (1, 2, 3):
+    for variant in (1, 2, 3, 4):
         got = ctx.run("atomic", R, S, buildVariant=variant)
         check_oa(got, want)
     got = ctx.run("prj", R, S)

@@ -73,3 +73,49 @@ def test_sweep_harness_smoke_on_gpu():
                                "totalMatches", "inputSum"]
     auto = {l["shuffleRange"]: l["algoUsed"] for l in lines if l["algo"] == "auto"}
     assert auto[1] == "atomic" and auto[16] == "atomic"                          # locality: the table join
+
+
+def test_motivation_pins_equal_the_reference_logs(golden_dir):
+    """--protocol motivation asserts, at 2^27: PRO's "Results" = the value of every block of motivation_log* (the closed
+    form at NUM_RADIX_BITS 14), and for the build-only runs the sums AtomicsVsHTMVsNoCC_log1:1-6 hold."""
+    logs = json.load(open(os.path.join(golden_dir, "reference_logs.json")))
+    n = 1 << 27
+    tri = n * (n + 1) // 2
+    assert sweep.expected("prj", n, 14)["results"] == 549688705024
+    seen = 0
+    for c in logs["cases"]:
+        if c["script"] != "experiments/AtomicsVsHTMVsNoCC.sh":
+            continue
+        seen += 1
+        assert c["inputSum"] == tri and c.get("conflicts", c.get("conflictCount")) == 0
+        assert c["outputSum"] == (tri - n if c["algo"] == "nocc" else tri)
+    assert seen >= 6
+
+
+def test_mc_pro_leg_runs_the_reference_binary():
+    """The CPU radix leg of the motivation protocol: oracle/_ref/mchashjoins (built from the reference's mc/src where it
+    lies) with motivation.sh's own flags, at a small size; its "Results" equals the closed form the harness asserts."""
+    if not os.path.exists(sweep.MC):
+        pytest.skip("oracle/_ref/mchashjoins not built (the reference's sources are not on this machine)")
+    n = 1 << 18
+    rows = sweep.mc_pro_lines(n, 16, 2, 2)
+    assert len(rows) == 2 and all(r["us"] > 0 for r in rows)
+    assert all(r["results"] == sweep.expected("prj", n, 14)["results"] for r in rows)
+
+
+@pytest.mark.gpu
+def test_motivation_protocol_smoke_on_gpu():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep.py"), "--protocol", "motivation", "--log2n", "20",
+                        "--repeats", "3", "--max-log2w", "5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    mot = [l for l in lines if l["protocol"] == "motivation.sh"]
+    avh = [l for l in lines if l["protocol"] == "AtomicsVsHTMVsNoCC.sh"]
+    for w in (1 << e for e in range(6)):
+        got = {(l["algo"], l["device"]) for l in mot if l["shuffleRange"] == w}
+        want = {("atomic", "hip"), ("htm", "hip"), ("prj", "hip"), ("nocc", "cpu"), ("atomic", "cpu")}
+        if os.path.exists(sweep.MC):
+            want.add(("PRO", "cpu"))
+        assert got == want, (w, got)
+    assert {(l["dataDistr"], l["algo"], l["device"]) for l in avh} >= {(d, a, "hip") for d in ("sorted", "shuffle") for a in ("atomic", "htm", "prj")}
+    assert all("totalMatches" not in l for l in lines)               # build only, as the reference's ENABLE_PROBE 0 binaries print

@@ -47,6 +47,10 @@ def traffic(fetch_json, write_json, out):
     res["_note"] = ("HBM bytes per launch, |R|=|S|=2^30 uniform, from separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of "
                     "`python3 bench.py --steps 2 --warmup 1 --no-extra --no-cpu-baseline`; per kernel name 2 * FETCH_SIZE + WRITE_SIZE "
                     "(template instances of one kernel summed per launch; see tools/summarize_prof.py: traffic)")
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_hash
+    res["_source_hash"] = kernel_source_hash()        # bench.py reports these bytes only while the kernel sources are these
     json.dump(res, open(out, "w"), indent=1)
 
 

@@ -16,6 +16,18 @@ conflicts 0, totalMatches = rSize, inputSum = N(N+1)/2, outputSum = the per-oper
 tests/golden/reference_logs.json; PRO's checksum in closed form), so a line that is printed is a line that is right.
 
     python tools/sweep.py [--log2n 27] [--repeats 5] [--no-cpu] [--max-log2w K] > profiles/rNN_sweep.jsonl
+
+--protocol motivation: the reference's OTHER sweep script, experiments/motivation.sh:9-31 -- the same windows, BUILD ONLY
+(its binaries were built with ENABLE_PROBE 0, config.h:4), with mc's radix join as the first leg:
+
+    for every W:   CPU  mc PRO, the reference's own binary built from its sources (oracle/_ref/mchashjoins --algo=PRO
+                        --r-size=2^27 --s-size=2 --local-shuffle-range=W), its printed "Results" asserted against the value
+                        every block of experiments/new_backup/motivation_log* holds (549688705024 at 2^27 = the closed form)
+                   CPU  nocc and atomic build-only (`main --algo nocc|cpu-atomic --probe 0`)
+                   GPU  atomic / htm / prj build-only (table build; bucketised table build; partition R + per-partition
+                        tables = what PRO does in this fork)
+    then experiments/AtomicsVsHTMVsNoCC.sh:6-11: build-only on `sorted` and `shuffle`, CPU and GPU, asserted against
+    experiments/new_backup/AtomicsVsHTMVsNoCC_log1:1-6 (conflicts 0, inputSum, the two outputSum values)
 """
 import argparse
 import json
@@ -70,14 +82,130 @@ def cpu_lines(algo, n, window, repeats):
     return [json.loads(l) for l in out.splitlines() if l.startswith("{")]
 
 
+MC = os.path.join(ROOT, "oracle", "_ref", "mchashjoins")
+
+
+def effective_cpus():
+    sys.path.insert(0, ROOT)
+    from bench import effective_cpus as f
+    return f()
+
+
+def mc_pro_lines(n, window, repeats, threads):
+    """mc PRO from the reference's sources, motivation.sh:11 (s-size 2: the fork's PRO ignores S). One dict per repeat."""
+    import re
+    rows = []
+    for _ in range(repeats):
+        out = subprocess.run([MC, f"--nthreads={threads}", f"--r-size={n}", "--s-size=2", "--algo=PRO",
+                              f"--local-shuffle-range={window}"], capture_output=True, text=True, check=True).stdout
+        rows.append({"us": float(re.search(r"TOTAL-TIME-USECS[^\n]*\n\s*([0-9.]+)", out).group(1)),
+                     "results": int(re.search(r"Results = (\d+)\. DONE", out).group(1))})
+    return rows
+
+
+def cpu_build_only(algo, n, dist, window, repeats):
+    out = subprocess.run([MAIN, "--algo", algo, "--rSize", str(n), "--probeLength", "4", "--dataDistr", dist,
+                          "--shuffleRange", str(window), "--probe", "0", "--repeat", str(repeats)],
+                         capture_output=True, text=True, check=True).stdout
+    return [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+
+
+def motivation(a, hj):
+    """experiments/motivation.sh + AtomicsVsHTMVsNoCC.sh (see the module docstring)."""
+    n = 1 << a.log2n
+    top = a.log2n if a.max_log2w is None else min(a.max_log2w, a.log2n)
+    tri = n * (n + 1) // 2
+    threads = min(64, effective_cpus())
+    have_mc = os.path.exists(MC) and not a.no_cpu
+
+    def emit(line):
+        line["mtuples_per_s"] = n / max(line["hashBuildTimeInMicroseconds"], 1)        # build only: |R| / t, as BASELINE.md quotes
+        print(json.dumps(line), flush=True)
+
+    def gpu_build_only(ctxs, dR, tag):
+        ctx, hctx, pctx = ctxs
+        runs, last = [], None
+        for _ in range(a.repeats):
+            ctx.build(dR, n); ctx.checksums()
+            last = ctx.fetch()
+            for k, v in (("conflicts", 0), ("inputSum", tri), ("outputSum", tri)):
+                assert last[k] == v, (k, last[k], v, tag)
+            runs.append(last["build_us"] + last["clear_us"])
+        emit({"algo": "atomic", "rSize": n, "probeLength": 4, **summarise(runs), "conflicts": 0, "inputSum": last["inputSum"],
+              "outputSum": last["outputSum"], **tag, "device": "hip", "buildVariant": last["buildVariant"], "probe": 0})
+        runs = []
+        for _ in range(a.repeats):
+            hctx.build(dR, n); hctx.checksums()
+            last = hctx.fetch()
+            for k, v in (("conflicts", 0), ("inputSum", tri), ("outputSum", tri)):
+                assert last[k] == v, (k, last[k], v, tag)
+            runs.append(last["build_us"] + last["clear_us"])
+        emit({"algo": "htm", "rSize": n, "transactionSize": 16, "probeLength": 4, **summarise(runs), "conflictCount": 0,
+              "failedTransactions": 0, "inputSum": last["inputSum"], "outputSum": last["outputSum"], **tag, "device": "hip",
+              "buildVariant": last["buildVariant"], "probe": 0})
+        runs = []
+        for _ in range(a.repeats):
+            pctx.prj_join(dR, n, 0, 0)
+            last = pctx.fetch()
+            assert last["prjChecksum"] == expected("prj", n, last["radixBits"])["results"], (last, tag)
+            runs.append(last["total_us"])
+        emit({"algo": "prj", "rSize": n, **summarise(runs), "results": last["prjChecksum"], "radixBits": last["radixBits"], **tag,
+              "device": "hip", "probe": 0})
+
+    with hj.HashJoinContext(0) as ctx, hj.HashJoinContext(0) as hctx, hj.HashJoinContext(0) as pctx:
+        dR = ctx.dev_alloc(n * 8)
+        ctx.reserve("atomic", n, 0); hctx.reserve("htm", n, 0); pctx.reserve("prj", n, 0)
+        for e in range(0, top + 1):
+            W = 1 << e
+            tag = {"dataDistr": "local_shuffle", "shuffleRange": W, "protocol": "motivation.sh"}
+            if have_mc:
+                rows = mc_pro_lines(n, W, a.repeats, threads)
+                want = expected("prj", n, 14)["results"]          # NUM_RADIX_BITS 14 (prj_params.h:16): 549688705024 at 2^27
+                for r in rows:
+                    assert r["results"] == want, (r, want)
+                emit({"algo": "PRO", "rSize": n, **summarise([r["us"] for r in rows]), "results": want, **tag, "device": "cpu",
+                      "kind": "reference (mc/src compiled where it lies: oracle/_ref/mchashjoins)", "cpu_threads": threads})
+            if not a.no_cpu:
+                for algo, name, osum in (("nocc", "nocc", tri - n), ("cpu-atomic", "atomic", tri)):
+                    rows = cpu_build_only(algo, n, "local_shuffle", W, a.repeats)
+                    for r in rows:
+                        assert (r["conflicts"], r["inputSum"], r["outputSum"]) == (0, tri, osum), r
+                    emit({"algo": name, "rSize": n, "probeLength": 4, **summarise([r["hashBuildTimeInMicroseconds"] for r in rows]),
+                          "conflicts": 0, "inputSum": tri, "outputSum": osum, **tag, "device": "cpu", "cpu_threads": rows[0]["cpu_threads"], "probe": 0})
+            R = hj.generate_data("local_shuffle", n, n, W)
+            ctx.copy_h2d(dR, R)
+            del R
+            gpu_build_only((ctx, hctx, pctx), dR, tag)
+        # experiments/AtomicsVsHTMVsNoCC.sh:6-11
+        for dist in ("sorted", "shuffle"):
+            tag = {"dataDistr": dist, "shuffleRange": 16, "protocol": "AtomicsVsHTMVsNoCC.sh"}
+            if not a.no_cpu:
+                for algo, name, osum in (("nocc", "nocc", tri - n), ("cpu-atomic", "atomic", tri)):
+                    rows = cpu_build_only(algo, n, dist, 16, a.repeats)
+                    for r in rows:
+                        assert (r["conflicts"], r["inputSum"], r["outputSum"]) == (0, tri, osum), r      # AtomicsVsHTMVsNoCC_log1:1-4
+                    emit({"algo": name, "rSize": n, "probeLength": 4, **summarise([r["hashBuildTimeInMicroseconds"] for r in rows]),
+                          "conflicts": 0, "inputSum": tri, "outputSum": osum, **tag, "device": "cpu", "cpu_threads": rows[0]["cpu_threads"], "probe": 0})
+            R = hj.generate_data(dist, n, n, 16)
+            ctx.copy_h2d(dR, R)
+            del R
+            gpu_build_only((ctx, hctx, pctx), dR, tag)
+        ctx.dev_free(dR)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log2n", type=int, default=27)
     ap.add_argument("--repeats", type=int, default=5, help="experiments/runner.sh: N=5")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--max-log2w", type=int, default=None, help="stop the window sweep early (default: up to rSize)")
+    ap.add_argument("--protocol", default="probe", choices=["probe", "motivation"],
+                    help="probe: experiments/probe.sh (build + probe); motivation: experiments/motivation.sh + "
+                         "AtomicsVsHTMVsNoCC.sh (build only, mc PRO as the CPU radix leg)")
     a = ap.parse_args()
     import htm_hashjoin_amd as hj
+    if a.protocol == "motivation":
+        return motivation(a, hj)
     n = 1 << a.log2n
     top = a.log2n if a.max_log2w is None else min(a.max_log2w, a.log2n)
     S = hj.generate_data("sorted", n)
