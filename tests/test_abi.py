@@ -36,7 +36,7 @@ def test_no_undeclared_exports():
 
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.hj_params) == 12 * 4
-    assert ctypes.sizeof(_lib.hj_result) == 12 * 8 + 2 * 4 + 7 * 8 + 4 * 8 + 8 + 3 * 8
+    assert ctypes.sizeof(_lib.hj_result) == 12 * 8 + 2 * 4 + 7 * 8 + 4 * 8 + 8 + 3 * 8 + 8     # + compactFallback (ABI 4)
 
 
 def test_abi_version_and_strerror():
