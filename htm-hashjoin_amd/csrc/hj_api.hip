@@ -45,6 +45,7 @@ struct hj_ctx {
     bool htmBuilt = false;
     uint32_t htmBuckets = 0;                    // numBuckets of the last htm build
     uint64_t* htmConflicts = nullptr; size_t capHtmConflicts = 0;       // bytes
+    uint32_t* htmOwnCounts = nullptr; size_t capHtmOwnCounts = 0;        // bytes: conflicts listed per chunk of the window build
     unsigned int* htmOvfCount = nullptr; uint32_t* htmOvfBase = nullptr; uint32_t* htmScan = nullptr; uint64_t capHtmBuckets = 0;
     uint64_t* htmOverflow = nullptr; uint64_t capHtmOverflow = 0;       // overflow buckets (index 0 unused)
     uint64_t htmOverflowUsed = 0;
@@ -220,7 +221,7 @@ void hj_destroy(hj_ctx* c)
     zipf_release(c);
     if (c->stream || !c->ownStream) hipStreamSynchronize(c->stream);
     void* frees[] = {c->table, c->dCtr, c->tmpA, c->partR, c->partS, c->work, c->stageR, c->stageS,
-                     c->ownerBuf, c->queueBuf, c->queueCount, c->fitCount, c->boundsBuf, c->htmConflicts, c->htmOvfCount,
+                     c->ownerBuf, c->queueBuf, c->queueCount, c->fitCount, c->boundsBuf, c->htmConflicts, c->htmOwnCounts, c->htmOvfCount,
                      c->htmOvfBase, c->htmScan, c->htmOverflow, c->shard[0].work, c->shard[1].work,
                      c->shard[2].work, c->shard[3].work};
     for (void* p : frees) if (p) hipFree(p);
@@ -292,7 +293,21 @@ int hj_reserve(hj_ctx* c, const hj_params* params, uint64_t rSize, uint64_t sSiz
         const uint64_t nb = htm_num_buckets(rSize);
         int rc = grow(c, c->table, c->tableCapSlots, 4 * nb + kTableSlack);
         if (rc) return rc;
-        const size_t qb = wave_queue_bytes(rSize, c->nCU), cb = wave_conflict_bytes(rSize, c->nCU);
+        // rings (variant 3), workgroup window (2) or global atomics (1): buffers for the larger need of the first two
+        size_t qb = wave_queue_bytes(rSize, c->nCU), cb = wave_conflict_bytes(rSize, c->nCU);
+        if (own_supported(4 * nb)) {
+            if (own_queue_bytes(rSize) > qb) qb = own_queue_bytes(rSize);
+            if (own_conflict_bytes(rSize, c->nCU) > cb) cb = own_conflict_bytes(rSize, c->nCU);
+            const size_t ob = own_owner_bytes(4 * nb), kb = own_conflict_count_bytes(rSize, c->nCU);
+            if (ob > c->capOwner) {
+                if (c->ownerBuf) { HJ_HIP(c, hipFree(c->ownerBuf)); c->ownerBuf = nullptr; c->capOwner = 0; }
+                HJ_HIP(c, hipMalloc(&c->ownerBuf, ob)); c->capOwner = ob;
+            }
+            if (kb > c->capHtmOwnCounts) {
+                if (c->htmOwnCounts) { HJ_HIP(c, hipFree(c->htmOwnCounts)); c->htmOwnCounts = nullptr; c->capHtmOwnCounts = 0; }
+                HJ_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->htmOwnCounts), kb)); c->capHtmOwnCounts = kb;
+            }
+        }
         if (qb > c->capQueue) {
             if (c->queueBuf) { HJ_HIP(c, hipFree(c->queueBuf)); c->queueBuf = nullptr; c->capQueue = 0; }
             HJ_HIP(c, hipMalloc(&c->queueBuf, qb)); c->capQueue = qb;
@@ -343,13 +358,13 @@ int hj_reserve(hj_ctx* c, const hj_params* params, uint64_t rSize, uint64_t sSiz
 //      W=2^12 defers 36 % and runs 12.9 ms against 5.8);
 //   1  global atomics otherwise (no locality: hj_join_dev(AUTO) then takes the radix join instead).
 static int sample_variant(hj_ctx* c, const void* d, bool key32, uint64_t n, uint64_t tableSize, uint32_t hshift,
-                          bool canOwn, bool canWave, uint32_t* variant)
+                          bool canOwn, bool canWave, uint32_t* variant, bool canCompact = false, bool htm = false)
 {
     const uint32_t nSample = 256;
-    HJ_HIP(c, launch_sample_locality(d, key32, n, tableSize, hshift, nSample, c->fitCount, c->stream));
+    HJ_HIP(c, launch_sample_locality(d, key32, n, tableSize, hshift, nSample, c->fitCount, c->stream, htm));
     HJ_HIP(c, hipMemcpyAsync(c->hFit, c->fitCount, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
     HJ_HIP(c, hipStreamSynchronize(c->stream));
-    *variant = variant_for_sample(c->hFit[0], c->hFit[1], c->hFit[2], canOwn, canWave);
+    *variant = variant_for_sample(c->hFit[0], c->hFit[1], c->hFit[2], canOwn, canWave, canCompact, c->hFit[3]);
     return HJ_OK;
 }
 
@@ -374,7 +389,6 @@ static int build_common(hj_ctx* c, const void* d, bool key32, uint64_t n, uint32
     const uint32_t pl = probe_len(c->params);
     const bool canCompact = canWave && wave_compact_supported(tableSize, pl);
     if (variant == 4 && !canCompact) variant = 3;
-    if (variant == 3 && c->forceVariant && canCompact) variant = 4;      // hj_join_dev(AUTO) sampled "rings": the compact ones first
     if (variant == 3 && !canWave) variant = canOwn ? 2 : 1;
     if (variant == 2 && !canOwn) variant = 1;
     if (variant == 0 && !canOwn && !canWave) variant = 1;
@@ -477,15 +491,28 @@ static int build_htm(hj_ctx* c, const uint64_t* dR, uint64_t rSize, uint64_t idx
     HJ_HIP(c, hipMemsetAsync(c->dCtr, 0, sizeof(Counters), c->stream));
     int rc;
     if ((rc = record(c, EV_CLEAR0))) return rc;
-    // locality pre-round on the key order (bucket = key / 3 keeps it): rings if they will do, else global atomics
-    uint32_t variant = c->params.buildVariant == 1 ? 1 : 3;
-    if (!wave_supported(slots)) variant = 1;
-    if (variant == 3 && c->params.buildVariant == 0 &&
-        (rc = sample_variant(c, dR, false, rSize, slots, 0, false, true, &variant))) return rc;
+    // locality pre-round with the bucketised table's own hash (bucket = key / 3 keeps the key order): the rings if they
+    // will do, the workgroup window for looser locality (shuffle windows up to ~2000 positions), else global atomics
+    const bool canWave = wave_supported(slots);
+    const bool canOwn = own_supported(slots) && c->capOwner >= own_owner_bytes(slots) && c->capQueue >= own_queue_bytes(rSize) &&
+                        c->capHtmConflicts >= own_conflict_bytes(rSize, c->nCU) && c->capHtmOwnCounts >= own_conflict_count_bytes(rSize, c->nCU);
+    uint32_t variant = c->params.buildVariant > 3 ? 3 : c->params.buildVariant;
+    if (variant == 0 && (canWave || canOwn) &&
+        (rc = sample_variant(c, dR, false, rSize, slots, 0, canOwn, canWave, &variant, false, true))) return rc;
+    if (variant == 0) variant = 1;
+    if (variant == 3 && !canWave) variant = canOwn ? 2 : 1;
+    if (variant == 2 && !canOwn) variant = 1;
     c->variantUsed = variant; c->algoUsed = HJ_ALGO_HTM;
-    const WaveSlices sl = wave_conflict_layout(rSize, c->nCU, c->boundsBuf);
+    const WaveSlices sl = variant == 2 ? own_conflict_layout(rSize, c->nCU, c->htmOwnCounts) : wave_conflict_layout(rSize, c->nCU, c->boundsBuf);
     const KernelEvents kevW{c->ev[EV_KW0], c->ev[EV_KW1]};
-    if (variant == 3) {
+    const KernelEvents kevO{c->ev[EV_KO0], c->ev[EV_KO1]};
+    if (variant == 2) {
+        if ((rc = record(c, EV_BUILD0))) return rc;
+        HJ_HIP(c, launch_build_own(dR, false, rSize, 0, c->table, slots, 3, idxBase, ShardCheck{0, 0, 0, 0}, c->nCU, c->ownerBuf,
+                                   c->queueBuf, c->queueCount, c->dCtr, Gate{nullptr, 0}, 3, c->ev[EV_BUILD_A], c->stream, &kevO,
+                                   c->htmConflicts, c->htmOwnCounts));
+        c->evSet[EV_BUILD_A] = c->evSet[EV_KO0] = c->evSet[EV_KO1] = true;
+    } else if (variant == 3) {
         if ((rc = record(c, EV_BUILD0))) return rc;
         HJ_HIP(c, launch_build_wave(dR, false, rSize, 0, c->table, slots, 3, idxBase, ShardCheck{0, 0, 0, 0}, c->nCU, c->boundsBuf,
                                     c->queueBuf, c->dCtr, Gate{nullptr, 0}, kWaveAll, c->ev[EV_BUILD_A], c->stream, c->htmConflicts, kWaveClassic, 3, &kevW));
@@ -627,8 +654,9 @@ int hj_join_dev(hj_ctx* c, const uint64_t* dR, uint64_t rSize, const uint64_t* d
                             c->capQueue >= own_queue_bytes(rSize);
         const bool canWave = wave_supported(2 * rSize) && c->capQueue >= wave_queue_bytes(rSize, c->nCU);
         uint32_t v = 1;
+        const bool canCompact = canWave && wave_compact_supported(2 * rSize, probe_len(c->params));
         if ((canOwn || canWave) && c->params.buildVariant != 1 &&
-            (rc = sample_variant(c, dR, false, rSize, 2 * rSize, 0, canOwn, canWave, &v))) return rc;
+            (rc = sample_variant(c, dR, false, rSize, 2 * rSize, 0, canOwn, canWave, &v, canCompact))) return rc;
         // no locality: both table phases would be random HBM accesses. Loose locality (variant 2) pays for every tuple
         // that leaves its window with global atomics: at 2^27, local_shuffle W=2^11 (3.8 % deferred) the table join
         // takes 2.06 ms against the radix join's 1.89 ms, at W=2^10 0.99 against 1.88 (profiles/r02_sweep.jsonl): the

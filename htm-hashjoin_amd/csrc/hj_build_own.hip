@@ -105,18 +105,24 @@ constexpr int kQCap = 128;                        // per-wavefront retry queue e
 //               atomicMin) run on 64 queue entries at a time, so every round is dense regardless of
 //               how long individual probe/displacement chains get.
 // All per-tuple arithmetic is 32-bit: key = low word, slot numbers < 2^32, value = {key, index}.
-template <bool KEY32, bool CHECK = false>
+// HTM = true: the bucketised table of --algo htm (hj_device.h, home_slot_htm: every tuple of a bucket has the bucket's
+// first slot as its home, probeLen = 3); a tuple that runs out of budget is one of the reference's conflicts
+// (HTMHashBuild.hpp:181-183) and is appended, as (index << 32 | key), to this workgroup's slice of htmConflicts
+// (confSlice entries per workgroup; ccounts[workgroup] = how many) for the chain phase (hj_htm.hip).
+template <bool KEY32, bool CHECK = false, bool HTM = false>
 __global__ void __launch_bounds__(kOwnThreads, 4)
 k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
             uint64_t* __restrict__ table, uint64_t mask, uint32_t hshift, uint32_t probeLen, uint64_t idxBase, ShardCheck sc,
             unsigned int* __restrict__ owner, DeferredEntry* __restrict__ queue,
-            unsigned long long* __restrict__ queueCount, Counters* __restrict__ ctr, Gate gate)
+            unsigned long long* __restrict__ queueCount, Counters* __restrict__ ctr, Gate gate,
+            uint64_t* __restrict__ htmConflicts, uint32_t* __restrict__ ccounts, uint32_t confSlice)
 {
     if (gate_closed(gate)) return;
     extern __shared__ __align__(16) uint64_t win[];   // kWinSlots slots, ring indexed by (slot & (kWinSlots-1))
     __shared__ unsigned int owned[kWinBlocks];   // per ring block: 0 = not tried yet, 1 = claimed by this workgroup, 2 = someone else's
     __shared__ unsigned int need[kWinBlocks];    // per ring block: wanted by the current tile (count, or 0x10000 = unconditional)
     __shared__ unsigned int sTileMin;
+    __shared__ unsigned int sConf;               // HTM: conflicts this workgroup has listed so far
     __shared__ uint32_t qPos[kOwnThreads / 64][kQCap], qLo[kOwnThreads / 64][kQCap], qHi[kOwnThreads / 64][kQCap];
 
     const uint64_t cb = (uint64_t)blockIdx.x * chunkLen;
@@ -134,8 +140,10 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
 
     for (uint32_t i = threadIdx.x; i < kWinSlots; i += kOwnThreads) win[i] = kEmpty;
     if (threadIdx.x < kWinBlocks) { owned[threadIdx.x] = 0; need[threadIdx.x] = 0; }
-    if (threadIdx.x == 0) sTileMin = 0xFFFFFFFFu;
+    if (threadIdx.x == 0) { sTileMin = 0xFFFFFFFFu; sConf = 0; }
     __syncthreads();
+    uint64_t* const myConflicts = HTM ? htmConflicts + (uint64_t)blockIdx.x * confSlice : nullptr;
+    (void)myConflicts;
 
     uint32_t wb = 0;                 // window = table blocks [wb, wb + kWinBlocks)
     bool haveWin = false;            // false until the first tile with a valid tuple
@@ -149,7 +157,7 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
     // next state in place
     auto round_body = [&](uint32_t& pos, uint32_t& mlo, uint32_t& mhi, const bool has) -> bool {
         const uint32_t key = mlo;
-        uint32_t budget = probeLen - ((pos - ((key >> hshift) & mask32)) & mask32);
+        uint32_t budget = probeLen - ((pos - home32<HTM>(key, hshift, mask32)) & mask32);
         const uint32_t blk = pos >> kBlkShift;
         const bool ownOk = (blk - wb < kWinBlocks) & (((ownedMask >> (blk & (kWinBlocks - 1))) & 1u) != 0);
         const bool drop0 = has & (budget == 0);                           // NoCCHashBuild.hpp:57-58
@@ -178,6 +186,15 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
         mlo = disp ? (uint32_t)old : mlo; mhi = disp ? (uint32_t)(old >> 32) : mhi;
         const bool dropped = drop0 | drop1;
         drops += dropped ? 1u : 0u; dropSum += dropped ? (unsigned long long)key : 0ull;
+        if constexpr (HTM) {       // the bucket is full: one of the reference's conflicts, listed for the chain phase
+            const unsigned long long cm = __ballot(dropped);
+            if (cm) {
+                unsigned int base = 0;
+                if (lane == 0) base = atomicAdd(&sConf, (unsigned int)__popcll(cm));
+                base = (unsigned int)__shfl((int)base, 0, 64);
+                if (dropped) myConflicts[base + lane_rank(cm)] = mine;
+            }
+        }
         // deferred tuples leave for the global queue (one returning atomic per round that has any)
         const unsigned long long dm = __ballot(toDefer);
         if (dm) {
@@ -271,7 +288,7 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
             bad += (in & !okKey) ? 1u : 0u;
             if constexpr (CHECK) foreign += (in & is_foreign(klo[j], sc)) ? 1u : 0u;   // shard check: its own instance
             liveMask |= ok ? (1u << j) : 0u;
-            const uint32_t hb = ((klo[j] >> hshift) & mask32) >> kBlkShift;
+            const uint32_t hb = home32<HTM>(klo[j], hshift, mask32) >> kBlkShift;
             myMin = (ok & (hb < myMin)) ? hb : myMin;
         }
         myMin = wave_min_u32(myMin);
@@ -326,7 +343,7 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
         if (haveWin) {
 #pragma unroll
             for (int j = 0; j < kPerThread; ++j) {
-                const uint32_t home = (klo[j] >> hshift) & mask32;
+                const uint32_t home = home32<HTM>(klo[j], hshift, mask32);
                 const uint32_t hb = home >> kBlkShift;
                 const bool lv = (liveMask >> j) & 1u;
                 uint32_t r0 = (lv & (hb - wb < kWinBlocks)) ? (hb & (kWinBlocks - 1)) : 0xFFu;
@@ -374,7 +391,7 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
             const bool lv = (liveMask >> j) & 1u;
             uint32_t mlo = klo[j];
             uint32_t mhi = idx0 + tb + tOff + 64 * j;
-            uint32_t pos = (klo[j] >> hshift) & mask32;
+            uint32_t pos = home32<HTM>(klo[j], hshift, mask32);
             const uint32_t blk = pos >> kBlkShift;
             const bool own = lv & (blk - wb < kWinBlocks) & (((ownedMask >> (blk & (kWinBlocks - 1))) & 1u) != 0);
             const uint64_t mine = pack64(mhi, mlo);
@@ -409,6 +426,10 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
                 for (uint32_t v = threadIdx.x; v < kBlkSlots / 2; v += kOwnThreads) dst[v] = src[v];
             }
         }
+    }
+    if constexpr (HTM) {
+        __syncthreads();
+        if (threadIdx.x == 0) ccounts[blockIdx.x] = sConf;
     }
     // counters: one atomic per wavefront
     unsigned long long c0 = drops, c3 = bad | ((unsigned long long)foreign << 32), c4 = deferred;
@@ -496,34 +517,50 @@ k_clear_unowned(uint64_t* __restrict__ table, const unsigned int* __restrict__ o
     if (blockIdx.x == 0 && threadIdx.x < kTableSlack) table[tableSize + threadIdx.x] = kEmpty;
 }
 
-// Phase B: finish the probe walk of every deferred tuple with global atomics.
+// Phase B: finish the probe walk of every deferred tuple with global atomics. HTM: the tuples that run out of budget
+// here are conflicts too; they go to the list's LAST slice (one slot per tuple of the relation: everything may be
+// deferred), reserved with one atomic per wavefront.
+template <bool HTM>
 __global__ void __launch_bounds__(kBlock)
 k_build_deferred(const DeferredEntry* __restrict__ queue, const unsigned long long* __restrict__ queueCount,
                  uint64_t* __restrict__ table, uint64_t mask, uint32_t hshift, uint32_t probeLen,
-                 Counters* __restrict__ ctr, Gate gate)
+                 Counters* __restrict__ ctr, Gate gate, uint64_t* __restrict__ lastSlice, uint32_t* __restrict__ lastCount)
 {
     if (gate_closed(gate)) return;
     const unsigned long long nq = *queueCount;
     unsigned long long drops = 0, dropSum = 0;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < nq;
+    const unsigned long long nqUp = (nq + 63ull) & ~63ull;                  // whole wavefronts stay in the loop (ballots below)
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < nqUp;
          i += (unsigned long long)gridDim.x * kBlock) {
-        uint64_t mine = queue[i].packed;
-        uint64_t pos = queue[i].pos;
-        const uint64_t home0 = home_slot((uint32_t)mine, hshift, mask);
+        const bool has = i < nq;
+        uint64_t mine = has ? queue[i].packed : 0;
+        uint64_t pos = has ? queue[i].pos : 0;
+        const uint64_t home0 = home32<HTM>((uint32_t)mine, hshift, (uint32_t)mask);
         uint32_t budget = probeLen - (uint32_t)((pos - home0) & mask);
-        for (;;) {
-            if (budget == 0) { drops += 1; dropSum += (uint32_t)mine; break; }
+        bool dropped = false;
+        for (; has;) {
+            if (budget == 0) { drops += 1; dropSum += (uint32_t)mine; dropped = true; break; }
             const unsigned long long old =
                 atomicMin(reinterpret_cast<unsigned long long*>(table + pos), (unsigned long long)mine);
             if (old == kEmpty || old == mine) break;
             if (old > mine) {
                 mine = old;
-                const uint64_t home = home_slot((uint32_t)old, hshift, mask);
+                const uint64_t home = home32<HTM>((uint32_t)old, hshift, (uint32_t)mask);
                 budget = probeLen - ((uint32_t)((pos - home) & mask) + 1);
             } else {
                 budget -= 1;
             }
             pos = (pos + 1) & mask;
+        }
+        if constexpr (HTM) {
+            const unsigned long long cm = __ballot(dropped);
+            if (cm) {
+                const uint32_t lane = threadIdx.x & 63;
+                uint32_t base = 0;
+                if (lane == (uint32_t)__ffsll((long long)cm) - 1u) base = atomicAdd(lastCount, (uint32_t)__popcll(cm));
+                base = (uint32_t)__shfl((int)base, __ffsll((long long)cm) - 1, 64);
+                if (dropped) lastSlice[base + lane_rank(cm)] = mine;
+            }
         }
     }
 #pragma unroll
@@ -543,34 +580,42 @@ k_build_deferred(const DeferredEntry* __restrict__ queue, const unsigned long lo
 // (window base = the tile's lowest home block - kBackBlocks) and therefore be deferred, and the
 // same for the 8 KiB ring k_build_wave would place for each of the tile's eight wavefront tiles.
 // out[0] = tuples outside variant 2's window, out[1] = tuples looked at, out[2] = outside variant 3's ring.
-template <bool KEY32>
+template <bool KEY32, bool HTM = false>
 __global__ void __launch_bounds__(kBlock)
 k_sample_locality(const void* __restrict__ Rv, uint64_t n, uint64_t mask, uint32_t hshift, uint32_t nSample,
                   unsigned int* __restrict__ out)
 {
     using Elem = typename std::conditional<KEY32, uint32_t, uint64_t>::type;
     const Elem* __restrict__ R = static_cast<const Elem*>(Rv);
-    __shared__ unsigned int sMinBlk, sOutside, sOutsideWave;
+    __shared__ unsigned int sMinBlk, sOutside, sOutsideWave, sDup;
+    __shared__ unsigned int seen[(2 * kOwnTile) / 32];               // one bit per home slot of a tile's neighbourhood
     const uint64_t tiles = (n + kOwnTile - 1) / kOwnTile;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t s = blockIdx.x; s < nSample; s += gridDim.x) {
         const uint64_t tile = (tiles * s) / nSample;
         const uint64_t b = tile * kOwnTile, e = (b + kOwnTile < n) ? b + kOwnTile : n;
-        if (threadIdx.x == 0) { sMinBlk = 0xFFFFFFFFu; sOutside = 0; sOutsideWave = 0; }
+        if (threadIdx.x == 0) { sMinBlk = 0xFFFFFFFFu; sOutside = 0; sOutsideWave = 0; sDup = 0; }
+        for (uint32_t i = threadIdx.x; i < (2 * kOwnTile) / 32; i += kBlock) seen[i] = 0;
         __syncthreads();
         uint32_t lo = 0xFFFFFFFFu;
         for (uint64_t i = b + threadIdx.x; i < e; i += kBlock) {
-            const uint32_t hb = (uint32_t)(home_slot((uint32_t)R[i], hshift, mask) >> kBlkShift);
+            const uint32_t hb = (home32<HTM>((uint32_t)R[i], hshift, (uint32_t)mask) >> kBlkShift);
             lo = hb < lo ? hb : lo;
         }
         lo = wave_min_u32(lo);
         if (lane == 0 && lo != 0xFFFFFFFFu) atomicMin(&sMinBlk, lo);
         __syncthreads();
         const uint32_t wbase = sMinBlk > kBackBlocks ? sMinBlk - kBackBlocks : 0;
-        uint32_t outside = 0;
+        uint32_t outside = 0, dup = 0;
         for (uint64_t i = b + threadIdx.x; i < e; i += kBlock) {      // second sweep hits L2
-            const uint32_t hb = (uint32_t)(home_slot((uint32_t)R[i], hshift, mask) >> kBlkShift);
+            const uint32_t h = home32<HTM>((uint32_t)R[i], hshift, (uint32_t)mask);
+            const uint32_t hb = h >> kBlkShift;
             outside += (hb - wbase >= kWinBlocks) ? 1u : 0u;
+            // tuples whose home slot another tuple of the tile has too (out[3]): with tight locality a tile's home slots lie
+            // within about its own length, so one bit per slot of twice that tells -- the share of duplicate keys, which
+            // decides between the two ring builds (the compact table's forced rounds only pay where retry rounds are few)
+            const uint32_t d = (h - (sMinBlk << kBlkShift)) & (2 * kOwnTile - 1);
+            dup += (atomicOr(&seen[d >> 5], 1u << (d & 31)) >> (d & 31)) & 1u;
         }
         // variant 3: wavefront tiles of kWvTileTuples consecutive tuples; the ring of kWvRingGran granules ends just
         // above the tile's highest home granule but never starts above its lowest (k_build_wave's rule); each of this
@@ -580,7 +625,7 @@ k_sample_locality(const void* __restrict__ Rv, uint64_t n, uint64_t mask, uint32
             const uint64_t se = sb + kWvTileTuples < e ? sb + kWvTileTuples : e;
             uint32_t glo = 0xFFFFFFFFu, ghiInv = 0xFFFFFFFFu;
             for (uint64_t i = sb + lane; i < se; i += 64) {
-                const uint32_t g = (uint32_t)(home_slot((uint32_t)R[i], hshift, mask) >> kWvGranShift);
+                const uint32_t g = (home32<HTM>((uint32_t)R[i], hshift, (uint32_t)mask) >> kWvGranShift);
                 glo = g < glo ? g : glo; ghiInv = ~g < ghiInv ? ~g : ghiInv;
             }
             glo = wave_min_u32(glo);
@@ -588,7 +633,7 @@ k_sample_locality(const void* __restrict__ Rv, uint64_t n, uint64_t mask, uint32
             uint32_t gbase = top > kWvRingGran ? top - kWvRingGran : 0;
             gbase = gbase < glo ? gbase : glo;
             for (uint64_t i = sb + lane; i < se; i += 64) {
-                const uint32_t g = (uint32_t)(home_slot((uint32_t)R[i], hshift, mask) >> kWvGranShift);
+                const uint32_t g = (home32<HTM>((uint32_t)R[i], hshift, (uint32_t)mask) >> kWvGranShift);
                 outsideWave += (g - gbase >= kWvRingGran) ? 1u : 0u;
             }
         }
@@ -596,11 +641,13 @@ k_sample_locality(const void* __restrict__ Rv, uint64_t n, uint64_t mask, uint32
         for (int off = 32; off > 0; off >>= 1) {
             outside += __shfl_down(outside, off, 64);
             outsideWave += __shfl_down(outsideWave, off, 64);
+            dup += __shfl_down(dup, off, 64);
         }
         if (lane == 0 && outside) atomicAdd(&sOutside, outside);
         if (lane == 0 && outsideWave) atomicAdd(&sOutsideWave, outsideWave);
+        if (lane == 0 && dup) atomicAdd(&sDup, dup);
         __syncthreads();
-        if (threadIdx.x == 0) { atomicAdd(&out[0], sOutside); atomicAdd(&out[1], (unsigned int)(e - b)); atomicAdd(&out[2], sOutsideWave); }
+        if (threadIdx.x == 0) { atomicAdd(&out[0], sOutside); atomicAdd(&out[1], (unsigned int)(e - b)); atomicAdd(&out[2], sOutsideWave); atomicAdd(&out[3], sDup); }
         __syncthreads();
     }
 }
@@ -611,11 +658,14 @@ size_t own_owner_bytes(uint64_t tableSize) { return ((tableSize >> kBlkShift) + 
 bool own_supported(uint64_t tableSize) { return tableSize >= (uint64_t)kWinSlots; }
 
 hipError_t launch_sample_locality(const void* R, bool key32, uint64_t n, uint64_t tableSize, uint32_t hshift, uint32_t nSample,
-                                  unsigned int* fitCount, hipStream_t s)
+                                  unsigned int* fitCount, hipStream_t s, bool htm)
 {
     const hipError_t e = hipMemsetAsync(fitCount, 0, 4 * sizeof(unsigned int), s);
     if (e != hipSuccess) return e;
-    if (key32)
+    if (htm)        // the bucketised table's own hash ((key / 3) << 2: the keys spread 4/3 as wide as in the open-addressing table)
+        hipLaunchKernelGGL((k_sample_locality<false, true>), dim3(nSample < 256 ? nSample : 256), dim3(kBlock), 0, s,
+                           R, n, tableSize - 1, hshift, nSample, fitCount);
+    else if (key32)
         hipLaunchKernelGGL(k_sample_locality<true>, dim3(nSample < 256 ? nSample : 256), dim3(kBlock), 0, s,
                            R, n, tableSize - 1, hshift, nSample, fitCount);
     else
@@ -628,7 +678,8 @@ hipError_t own_set_attributes()
 {
     // hipFuncAttributeMaxDynamicSharedMemorySize is per device: hj_create calls this with its device current
     const void* ks[] = {reinterpret_cast<const void*>(k_build_own<false, false>), reinterpret_cast<const void*>(k_build_own<true, false>),
-                        reinterpret_cast<const void*>(k_build_own<false, true>), reinterpret_cast<const void*>(k_build_own<true, true>)};
+                        reinterpret_cast<const void*>(k_build_own<false, true>), reinterpret_cast<const void*>(k_build_own<true, true>),
+                        reinterpret_cast<const void*>(k_build_own<false, false, true>)};
     for (const void* k : ks) {
         const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kWinSlots * sizeof(uint64_t));
         if (e != hipSuccess) return e;
@@ -636,16 +687,9 @@ hipError_t own_set_attributes()
     return hipSuccess;
 }
 
-hipError_t launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshift, uint64_t* table,
-                            uint64_t tableSize, uint32_t probeLen, uint64_t idxBase, ShardCheck sc, int nCU, void* ownerBuf,
-                            void* queueBuf, unsigned long long* queueCount, Counters* ctr, Gate gate, int parts,
-                            hipEvent_t evPhaseA, hipStream_t s, const KernelEvents* kev)
+// chunk geometry of the workgroup-window build: (chunks, tuples per chunk)
+static void own_geometry(uint64_t n, int nCU, uint64_t* nChunksOut, uint64_t* chunkLenOut)
 {
-    const uint32_t numBlocks = (uint32_t)(tableSize >> kBlkShift);
-    hipError_t e;
-    if (parts & 1) {
-    if ((e = hipMemsetAsync(ownerBuf, 0, own_owner_bytes(tableSize), s)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(queueCount, 0, sizeof(unsigned long long), s)) != hipSuccess) return e;
     // one chunk per resident workgroup (2 per CU: 76 KiB LDS each): a single wave of workgroups, no tail,
     // and the fewest chunk seams (measured: 512 chunks beat 768/1024/2048/4096 on MI355X)
     const int resident = 2 * (nCU > 0 ? nCU : 256);
@@ -655,14 +699,54 @@ hipError_t launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshi
     uint64_t chunkLen = (n + nChunks - 1) / nChunks;
     chunkLen = (chunkLen + kOwnTile - 1) / kOwnTile * kOwnTile;
     if (chunkLen < (uint64_t)kOwnTile * 4) chunkLen = (uint64_t)kOwnTile * 4;
-    const unsigned grid = (unsigned)((n + chunkLen - 1) / chunkLen);
+    *chunkLenOut = chunkLen;
+    *nChunksOut = (n + chunkLen - 1) / chunkLen;
+}
+// htm: the conflict list of the window build = one slice per chunk + a last slice for the deferred phase's conflicts
+WaveSlices own_conflict_layout(uint64_t n, int nCU, void* countsBuf)
+{
+    uint64_t nChunks, chunkLen;
+    own_geometry(n, nCU, &nChunks, &chunkLen);
+    return WaveSlices{(uint32_t)nChunks + 1, (uint32_t)chunkLen, static_cast<const uint32_t*>(countsBuf)};
+}
+size_t own_conflict_bytes(uint64_t n, int nCU)
+{
+    uint64_t nChunks, chunkLen;
+    own_geometry(n, nCU, &nChunks, &chunkLen);
+    return (size_t)(nChunks * chunkLen + n + 64) * sizeof(uint64_t);
+}
+size_t own_conflict_count_bytes(uint64_t n, int nCU)
+{
+    uint64_t nChunks, chunkLen;
+    own_geometry(n, nCU, &nChunks, &chunkLen);
+    return (size_t)(nChunks + 2) * sizeof(uint32_t);
+}
+
+hipError_t launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshift, uint64_t* table,
+                            uint64_t tableSize, uint32_t probeLen, uint64_t idxBase, ShardCheck sc, int nCU, void* ownerBuf,
+                            void* queueBuf, unsigned long long* queueCount, Counters* ctr, Gate gate, int parts,
+                            hipEvent_t evPhaseA, hipStream_t s, const KernelEvents* kev, uint64_t* htmConflicts, uint32_t* htmCounts)
+{
+    const bool htm = htmConflicts != nullptr;
+    if (htm && (key32 || probeLen != 3 || sc.mask || hshift)) return hipErrorInvalidValue;
+    const uint32_t numBlocks = (uint32_t)(tableSize >> kBlkShift);
+    uint64_t nChunks, chunkLen;
+    own_geometry(n, nCU, &nChunks, &chunkLen);
+    hipError_t e;
+    if (parts & 1) {
+    if ((e = hipMemsetAsync(ownerBuf, 0, own_owner_bytes(tableSize), s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(queueCount, 0, sizeof(unsigned long long), s)) != hipSuccess) return e;
+    if (htm && (e = hipMemsetAsync(htmCounts, 0, own_conflict_count_bytes(n, nCU), s)) != hipSuccess) return e;
+    const unsigned grid = (unsigned)nChunks;
     if (kev && (e = hipEventRecord(kev->before, s)) != hipSuccess) return e;
-#define HJ_OWN_LAUNCH(K32, CHK)                                                                                      \
-    hipLaunchKernelGGL((k_build_own<K32, CHK>), dim3(grid), dim3(kOwnThreads), kWinSlots * sizeof(uint64_t), s,       \
+#define HJ_OWN_LAUNCH(K32, CHK, HTM)                                                                                 \
+    hipLaunchKernelGGL((k_build_own<K32, CHK, HTM>), dim3(grid), dim3(kOwnThreads), kWinSlots * sizeof(uint64_t), s,  \
                        R, n, chunkLen, table, tableSize - 1, hshift, probeLen, idxBase, sc,                            \
-                       static_cast<unsigned int*>(ownerBuf), static_cast<DeferredEntry*>(queueBuf), queueCount, ctr, gate)
-    if (sc.mask) { if (key32) HJ_OWN_LAUNCH(true, true); else HJ_OWN_LAUNCH(false, true); }   // the instances that count foreign tuples
-    else { if (key32) HJ_OWN_LAUNCH(true, false); else HJ_OWN_LAUNCH(false, false); }
+                       static_cast<unsigned int*>(ownerBuf), static_cast<DeferredEntry*>(queueBuf), queueCount, ctr, gate, \
+                       htmConflicts, htmCounts, (uint32_t)chunkLen)
+    if (htm) HJ_OWN_LAUNCH(false, false, true);
+    else if (sc.mask) { if (key32) HJ_OWN_LAUNCH(true, true, false); else HJ_OWN_LAUNCH(false, true, false); }   // the instances that count foreign tuples
+    else { if (key32) HJ_OWN_LAUNCH(true, false, false); else HJ_OWN_LAUNCH(false, false, false); }
 #undef HJ_OWN_LAUNCH
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (kev && (e = hipEventRecord(kev->after, s)) != hipSuccess) return e;
@@ -672,20 +756,24 @@ hipError_t launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshi
     hipLaunchKernelGGL(k_finalize_range, dim3(1), dim3(64), 0, s, ctr, numBlocks, tableSize, gate);
     hipLaunchKernelGGL(k_clear_unowned, dim3(2048), dim3(kBlock), 0, s, table,
                        static_cast<const unsigned int*>(ownerBuf), ctr, numBlocks, tableSize, gate);
-    launch_build_deferred(queueBuf, queueCount, table, tableSize, hshift, probeLen, ctr, gate, s);
+    if (htm)
+        hipLaunchKernelGGL(k_build_deferred<true>, dim3(1024), dim3(kBlock), 0, s, static_cast<const DeferredEntry*>(queueBuf), queueCount,
+                           table, tableSize - 1, hshift, probeLen, ctr, gate, htmConflicts + nChunks * chunkLen, htmCounts + nChunks);
+    else launch_build_deferred(queueBuf, queueCount, table, tableSize, hshift, probeLen, ctr, gate, s);
     return hipGetLastError();
 }
 
 void launch_build_deferred(const void* queueBuf, const unsigned long long* queueCount, uint64_t* table, uint64_t tableSize,
                            uint32_t hshift, uint32_t probeLen, Counters* ctr, Gate gate, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_build_deferred, dim3(1024), dim3(kBlock), 0, s,
-                       static_cast<const DeferredEntry*>(queueBuf), queueCount, table, tableSize - 1, hshift, probeLen, ctr, gate);
+    hipLaunchKernelGGL(k_build_deferred<false>, dim3(1024), dim3(kBlock), 0, s,
+                       static_cast<const DeferredEntry*>(queueBuf), queueCount, table, tableSize - 1, hshift, probeLen, ctr, gate,
+                       nullptr, nullptr);
 }
 
 __global__ void k_pick_variant(const unsigned int* __restrict__ fit, bool canOwn, bool canWave, bool canCompact, Counters* __restrict__ ctr)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) ctr->variant = variant_for_sample(fit[0], fit[1], fit[2], canOwn, canWave, canCompact);
+    if (threadIdx.x == 0 && blockIdx.x == 0) ctr->variant = variant_for_sample(fit[0], fit[1], fit[2], canOwn, canWave, canCompact, fit[3]);
 }
 
 void launch_pick_variant(const unsigned int* fitCount, bool canOwn, bool canWave, Counters* ctr, hipStream_t s, bool canCompact)

@@ -220,10 +220,17 @@ k_wave_bounds_scan(const uint32_t* __restrict__ raw, uint32_t nChunks, uint32_t 
     // maximum over the valid samples of every chunk before this workgroup's (kNone = no sample = contributes nothing)
     uint32_t before = 0;
     bool any = false;
-    for (uint32_t k = t; k < base; k += kBlock) {
-        const uint32_t v = raw[k];
-        before = (v != kNone && v > before) ? v : before;
-        any |= v != kNone;
+    {   // 16-byte loads, four in flight per thread: the loop is a chain of L2 round trips otherwise (34 us for 32768 chunks)
+        const uint4* raw4 = reinterpret_cast<const uint4*>(raw);          // raw is the start of a hipMalloc'ed buffer; base % 256 == 0
+        const uint32_t nv = base >> 2;
+        auto take = [&](uint32_t v) { before = (v != kNone && v > before) ? v : before; any |= v != kNone; };
+        uint32_t k = t;
+        for (; k + 3 * kBlock < nv; k += 4 * kBlock) {
+            const uint4 a = raw4[k], b = raw4[k + kBlock], c4 = raw4[k + 2 * kBlock], d = raw4[k + 3 * kBlock];
+            take(a.x); take(a.y); take(a.z); take(a.w); take(b.x); take(b.y); take(b.z); take(b.w);
+            take(c4.x); take(c4.y); take(c4.z); take(c4.w); take(d.x); take(d.y); take(d.z); take(d.w);
+        }
+        for (; k < nv; k += kBlock) { const uint4 a = raw4[k]; take(a.x); take(a.y); take(a.z); take(a.w); }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(before, off, 64); before = o > before ? o : before; }

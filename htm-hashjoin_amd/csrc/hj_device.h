@@ -172,17 +172,22 @@ hipError_t launch_shard_scatter_ordered(const uint64_t* in, uint64_t n, uint32_t
 size_t own_queue_bytes(uint64_t rSize);
 size_t own_owner_bytes(uint64_t tableSize);
 bool   own_supported(uint64_t tableSize);
-// fitCount[0] = sampled tuples outside variant 2's window, [1] = tuples sampled, [2] = outside variant 3's ring
+// fitCount[0] = sampled tuples outside variant 2's window, [1] = tuples sampled, [2] = outside variant 3's ring,
+// [3] = sampled tuples that share their home slot with another tuple of their tile (duplicate keys)
 hipError_t launch_sample_locality(const void* R, bool key32, uint64_t n, uint64_t tableSize, uint32_t hshift, uint32_t nSample,
-                                  unsigned int* fitCount, hipStream_t s);
+                                  unsigned int* fitCount, hipStream_t s, bool htm = false);   // htm: the bucketised table's hash
 // the pre-round's decision on the device: ctr->variant = 3 / 2 / 1 by the same thresholds the host applies
 // (sample_thresholds below); canOwn / canWave: which variants have their buffers
 void launch_pick_variant(const unsigned int* fitCount, bool canOwn, bool canWave, Counters* ctr, hipStream_t s, bool canCompact = false);
 // variant worth taking for a sample (outside variant 2's window, tuples seen, outside variant 3's ring)
+// dup = sampled tuples that share their home slot with another tuple of their tile: rings with few duplicate keys take the
+// compact table (4: 2.6 against 3.4 ms build at 2^30 on unique keys, and a 4-byte probe), rings with many keep the classic
+// one (3): on `uniform` (37 % of the tuples repeat a key) the build is bound by the vector work of its retry rounds, the
+// compact build adds forced rounds to it (4.0 against 3.6 ms) and the whole step comes out even.
 __host__ __device__ inline uint32_t variant_for_sample(uint64_t outOwn, uint64_t seen, uint64_t outWave, bool canOwn, bool canWave,
-                                                      bool canCompact = false)
+                                                      bool canCompact = false, uint64_t dup = 0)
 {
-    if (canWave && outWave * 128 <= seen) return canCompact ? 4 : 3;
+    if (canWave && outWave * 128 <= seen) return (canCompact && dup * 8 <= seen) ? 4 : 3;
     if (canOwn && outOwn * 12 <= seen) return 2;
     return 1;
 }
@@ -192,7 +197,10 @@ hipError_t own_set_attributes();          // per device, at hj_create
 hipError_t launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshift, uint64_t* table,
                             uint64_t tableSize, uint32_t probeLen, uint64_t idxBase, ShardCheck sc, int nCU, void* ownerBuf,
                             void* queueBuf, unsigned long long* queueCount, Counters* ctr, Gate gate, int parts,
-                            hipEvent_t evPhaseA, hipStream_t s, const KernelEvents* kev = nullptr);   // parts: 1 = phase A (up to evPhaseA), 2 = the rest, 3 = both
+                            hipEvent_t evPhaseA, hipStream_t s, const KernelEvents* kev = nullptr,
+                            uint64_t* htmConflicts = nullptr, uint32_t* htmCounts = nullptr);   // parts: 1 = phase A (up to evPhaseA), 2 = the rest, 3 = both
+// htmConflicts != nullptr: the bucketised table of --algo htm through the workgroup window (tuples only, probeLen 3): the
+// tuples that find their bucket full are listed per chunk, plus one last slice for the deferred phase's (own_conflict_layout)
 
 // phase B alone: finishes the queued tuples with global atomics (shared with variant 3)
 void launch_build_deferred(const void* queueBuf, const unsigned long long* queueCount, uint64_t* table, uint64_t tableSize,
@@ -227,6 +235,9 @@ void launch_set_variant(Counters* ctr, uint32_t v, hipStream_t s);
 // tuple that runs out of budget is appended as (index << 32 | key) to its chunk's slice of htmConflicts (slices and
 // their counts as wave_conflict_layout describes)
 struct WaveSlices { uint32_t nChunks, sliceLen; const uint32_t* counts; };
+WaveSlices own_conflict_layout(uint64_t n, int nCU, void* countsBuf);
+size_t own_conflict_bytes(uint64_t n, int nCU);
+size_t own_conflict_count_bytes(uint64_t n, int nCU);
 WaveSlices wave_conflict_layout(uint64_t n, int nCU, void* boundsBuf);
 size_t wave_conflict_bytes(uint64_t n, int nCU);
 

@@ -24,6 +24,7 @@
 // (NoCCHashBuild.hpp:127-146), extra fields appended.
 
 #include "../../include/htm_hashjoin.h"
+#include "../../include/htm_hashjoin_sharded.h"
 
 #include <sched.h>
 
@@ -57,6 +58,8 @@ struct param_t {  // main.cpp:21-41, plus extensions at the end
     uint32_t radixBits = 0;
     int device = 0;
     int repeat = 1;
+    int gpus = 1;            // > 1: the radix-sharded join over devices 0 .. gpus-1 (libhtmjoin_sharded.so); 1 with --split: the same path on one GPU
+    std::string split;       // "" (single-GPU operator), "low" (key & (G-1)), "high" (range split)
 };
 
 void parseArgs(int argc, char** argv, param_t* p)
@@ -82,6 +85,8 @@ void parseArgs(int argc, char** argv, param_t* p)
         else if (strcmp(a, "--radixBits") == 0) p->radixBits = atoi(v);
         else if (strcmp(a, "--device") == 0) p->device = atoi(v);
         else if (strcmp(a, "--repeat") == 0) p->repeat = atoi(v);
+        else if (strcmp(a, "--gpus") == 0) p->gpus = atoi(v);
+        else if (strcmp(a, "--split") == 0) p->split = v;
         else {
             std::cout << "Found Unknown Arg: " << a << std::endl;
             exit(1);
@@ -217,6 +222,60 @@ int main(int argc, char* argv[])
         }
     }
     const uint64_t* S = p.probe ? relS.data() : nullptr;
+
+    if (!cpu && (p.gpus > 1 || !p.split.empty())) {
+        // ---- the radix-sharded join: rank g = device g holds the g-th contiguous piece of R and of S ----------------
+        if (p.algo != "atomic" && p.algo != "hip-atomic") { std::cerr << "--gpus / --split: the open-addressing operator (--algo atomic) shards" << std::endl; return 1; }
+        const int G = p.gpus;
+        std::vector<int> devs(G);
+        for (int g = 0; g < G; ++g) devs[g] = g;
+        hj_sharded* sh = nullptr;
+        int rc = hj_sharded_create(devs.data(), G, &sh);
+        if (rc != HJ_OK) { std::cerr << "hj_sharded_create(" << G << " devices): " << hj_strerror(rc) << std::endl; return 2; }
+        std::vector<const uint64_t*> dR(G), dS(G);
+        std::vector<uint64_t> nR(G), nS(G);
+        std::vector<void*> owned;
+        const double t0 = now_us();
+        for (int g = 0; g < G && rc == HJ_OK; ++g) {
+            const uint64_t rb = p.rSize * g / G, re = p.rSize * (g + 1) / G, sb = sSize * g / G, se = sSize * (g + 1) / G;
+            nR[g] = re - rb; nS[g] = S ? se - sb : 0;
+            void* d = nullptr;
+            if ((rc = hj_sharded_alloc(sh, g, (nR[g] + 2) * 8, &d)) != HJ_OK) break;
+            owned.push_back(d); dR[g] = static_cast<const uint64_t*>(d);
+            if ((rc = hj_sharded_copy_h2d(sh, g, d, relR.data() + rb, nR[g] * 8)) != HJ_OK) break;
+            if (S) {
+                if ((rc = hj_sharded_alloc(sh, g, (nS[g] + 2) * 8, &d)) != HJ_OK) break;
+                owned.push_back(d); dS[g] = static_cast<const uint64_t*>(d);
+                if ((rc = hj_sharded_copy_h2d(sh, g, d, S + sb, nS[g] * 8)) != HJ_OK) break;
+            }
+        }
+        const double h2d = now_us() - t0;
+        hj_params hp{};
+        hp.algo = HJ_ALGO_ATOMIC; hp.scaleOutput = p.scaleOutput; hp.numPartitions = p.numPartitions; hp.probeLength = p.probeLength;
+        const uint32_t split = p.split == "high" ? (uint32_t)HJ_SPLIT_HIGH : (uint32_t)HJ_SPLIT_LOW;
+        for (int rep = 0; rep < p.repeat && rc == HJ_OK; ++rep) {
+            hj_result r{};
+            hj_sharded_stats st{};
+            const double w0 = now_us();
+            rc = hj_sharded_join(sh, &hp, split, p.rSize, 0, dR.data(), nR.data(), S ? dS.data() : nullptr, S ? nS.data() : nullptr, &r, &st);
+            const double wall = now_us() - w0;
+            if (rc != HJ_OK) break;
+            std::cout << "{\"algo\": \"" << p.algo << "\",\"rSize\": " << p.rSize << ", \"probeLength\": " << p.probeLength
+                      << ", \"hashBuildTimeInMicroseconds\": " << (uint64_t)wall << ", \"conflicts\": " << r.conflicts;
+            if (p.probe) std::cout << ", \"totalMatches\": " << r.totalMatches;
+            std::cout << ", \"inputSum\": " << r.inputSum << ", \"outputSum\": " << r.outputSum
+                      << ", \"device\": \"hip\", \"n_gpus\": " << G << ", \"split\": \"" << (st.mode ? "high" : "low") << "\", \"mode\": " << st.mode
+                      << ", \"homeShift\": " << st.homeShift << ", \"keysMovedR\": " << st.keysMovedR << ", \"keysMovedS\": " << st.keysMovedS
+                      << ", \"maxMessageKeys\": " << st.maxMessageKeys << ", \"tableSizePerRank\": " << st.tableSizePerRank
+                      << ", \"sSize\": " << (S ? sSize : 0) << ", \"mtuples_per_s\": " << (double)(p.rSize + (S ? sSize : 0)) / wall
+                      << ", \"slowest_rank_build_us\": " << r.build_us << ", \"slowest_rank_probe_us\": " << r.probe_us
+                      << ", \"h2d_us\": " << h2d << "}" << std::endl;
+        }
+        if (rc != HJ_OK) std::cerr << "sharded join: " << hj_strerror(rc) << " (" << hj_sharded_last_error(sh) << ")" << std::endl;
+        for (size_t i = 0; i < owned.size(); ++i) hj_sharded_free(sh, (int)(i / (S ? 2 : 1)) , owned[i]);
+        hj_sharded_destroy(sh);
+        return rc == HJ_OK ? 0 : 2;
+    }
 
     for (int rep = 0; rep < p.repeat; ++rep) {
         if (cpu) {

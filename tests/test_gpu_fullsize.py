@@ -52,13 +52,13 @@ def test_metric_size_uniform_against_the_sequential_oracle():
         dR = c.dev_alloc(N * 8); c.copy_h2d(dR, R)
         dS = c.dev_alloc(N * 8); c.copy_h2d(dS, S)
         del R, S
-        for variant in (0, 3, 2):                  # what the bench runs (auto -> the compact rings), the classic rings, the workgroup window
+        for variant in (0, 4, 2):                  # what the bench runs (auto -> the classic rings: duplicate keys), the compact rings, the workgroup window
             c.reserve("atomic", N, N, buildVariant=variant)
             c.build(dR, N)
             c.probe(dS, N)
             c.checksums()
             got = c.fetch()
-            assert got["buildVariant"] == (4 if variant == 0 else variant) and got["compactFallback"] == 0
+            assert got["buildVariant"] == (3 if variant == 0 else variant) and got["compactFallback"] == 0
             for k in ("conflicts", "totalMatches", "inputSum", "tableSumHalf", "tableSumFull", "conflictSum"):
                 assert got[k] == want[k], (variant, k, got[k], want[k])
             assert got["outputSum"] == want["outputSumAtomic"]
@@ -71,9 +71,17 @@ def test_metric_size_uniform_against_the_sequential_oracle():
         c.probe_keys(dS, N)
         c.checksums()
         got = c.fetch()
-        assert got["buildVariant"] == 4 and got["compactFallback"] == 0
+        assert got["buildVariant"] == 3 and got["compactFallback"] == 0
         for k in ("conflicts", "totalMatches", "inputSum", "tableSumFull", "conflictSum"):
             assert got[k] == want[k], ("keys", k, got[k], want[k])
+        c.reserve("atomic", N, N, buildVariant=4)          # ... and the compact rings on the bare keys
+        c.build_keys(dR, N, 0, 2 * N)
+        c.probe_keys(dS, N)
+        c.checksums()
+        got = c.fetch()
+        assert got["buildVariant"] == 4 and got["compactFallback"] == 0
+        for k in ("conflicts", "totalMatches", "inputSum", "tableSumFull", "conflictSum"):
+            assert got[k] == want[k], ("keys compact", k, got[k], want[k])
         c.dev_free(dR); c.dev_free(dS)
     # the numbers every bench line of rounds 1 and 2 printed for this workload
     assert (want["conflicts"], want["totalMatches"]) == (180852797, 892889027)

@@ -115,14 +115,16 @@ def test_auto_variant_follows_locality(ctx):
     the LDS-window kernel, a random permutation the global-atomic one; results equal either way."""
     n = 1 << 20
     S = oracle.generate_data("sorted", n)
-    for dist, window, expect in (("uniform", 16, (4,)), ("sorted", 16, (4,)), ("local_shuffle", 16, (4,)), ("local_shuffle", 64, (3, 4)),
+    for dist, window, expect in (("uniform", 16, (3,)), ("sorted", 16, (4,)), ("local_shuffle", 16, (4,)), ("local_shuffle", 64, (3, 4)),
                                  ("local_shuffle", 1024, (2,)), ("shuffle", 16, (1,)), ("random", 16, (1,))):
         R = oracle.generate_data(dist, n, n, window)
         Sx = oracle.relS_for(dist, R)
         got = ctx.run("atomic", R, Sx)
-        # rings: the compact ones (4) where they hold, the classic ones (3) where the device handed over
+        # rings: the compact ones (4) on (nearly) unique keys where they hold, the classic ones (3) where the sample shows
+        # many duplicate keys (`uniform`: their retry rounds bound the build either way) or the device handed over
         assert got["buildVariant"] in expect, (dist, got["buildVariant"])
-        assert (got["buildVariant"] == 3) == (got["compactFallback"] != 0)
+        if dist == "uniform":
+            assert got["compactFallback"] == 0          # not tried
         check_oa(got, oracle.build_probe_seq(R, Sx, 4))
 
 
@@ -138,7 +140,7 @@ def test_algo_auto_switches_between_table_and_radix_join(ctx):
         got = ctx.run("auto", R, S)
         assert got["algoUsed"] == expect, (dist, window, got["algoUsed"])
         if expect == "atomic":
-            assert got["buildVariant"] == (2 if window == 1024 else 4)
+            assert got["buildVariant"] == (2 if window == 1024 else 3 if dist == "uniform" else 4)
             check_oa(got, oracle.build_probe_seq(R, S, 4))
         else:
             want = oracle.prj_join(R, S, got["radixBits"])
@@ -255,15 +257,15 @@ def test_operator_mirrors(ctx):
 
 
 # ---- the bucketised table of --algo htm ---------------------------------------------------------
-@pytest.mark.parametrize("variant", [0, 1, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("dist,window", [("uniform", 16), ("random", 16), ("sorted", 16), ("shuffle", 16),
                                          ("local_shuffle", 1024), ("local_shuffle", 65536)])
 @pytest.mark.parametrize("n", [1 << 10, 1 << 16, 1 << 20])
 def test_htm_bucket_table_matches_sequential_oracle(ctx, dist, window, n, variant):
     """HJ_ALGO_HTM against the sequential restatement of HTMHashBuild.hpp (oracle.htm_build_probe_seq): every counter,
     the primary buckets tuple for tuple (a bucket holds its three lowest-indexed tuples in input order), and every
-    overflow chain in walk order (head = newest overflow bucket). buildVariant 3 = the LDS rings, 1 = global atomics,
-    0 = whichever the locality pre-round picks: same table."""
+    overflow chain in walk order (head = newest overflow bucket). buildVariant 3 = the LDS rings, 2 = the workgroup
+    window (looser locality), 1 = global atomics, 0 = whichever the locality pre-round picks: same table."""
     R = oracle.generate_data(dist, n, n, window)
     S = oracle.relS_for(dist, R)
     want = oracle.htm_build_probe_seq(R, S, want_buckets=True)
@@ -275,7 +277,9 @@ def test_htm_bucket_table_matches_sequential_oracle(ctx, dist, window, n, varian
         want["overflowBuckets"], want["overflowSum"], want["outputSum"])
     assert got["totalMatches"] == oracle.true_cardinality(R, S)                 # every tuple is stored once: a correct join
     if variant:
-        assert got["buildVariant"] == variant
+        assert got["buildVariant"] == _variant_that_runs(variant, 4 * want["numBuckets"])
+    elif n >= 1 << 16:                         # the pre-round with the table's own hash: rings / window / global atomics
+        assert got["buildVariant"] == {("uniform", 16): 3, ("sorted", 16): 3, ("local_shuffle", 1024): 2}.get((dist, window), 1)
     buckets, overflows = ctx.export_buckets(want["numBuckets"])
     assert np.array_equal(buckets["tuples"], want["buckets"]["tuples"]) and np.array_equal(buckets["count"], want["buckets"]["count"])
     assert np.array_equal(buckets["nextIndex"] != 0, want["buckets"]["nextIndex"] != 0)
@@ -297,7 +301,7 @@ def test_htm_heavy_duplicates_odd_sizes_and_split_api(ctx):
         R = rng.integers(1, hi, size=n, dtype=np.uint64)
         S = rng.integers(1, hi + 5, size=2 * n + 3, dtype=np.uint64)
         want = oracle.htm_build_probe_seq(R, S, want_buckets=True)
-        for variant in (1, 3):
+        for variant in (1, 2, 3):
             with hj.HashJoinContext(0) as c:
                 dR = c.dev_alloc(n * 8 + 16); dS = c.dev_alloc(S.size * 8 + 16)
                 c.copy_h2d(dR + 8, R); c.copy_h2d(dS + 8, S)
@@ -322,9 +326,9 @@ def test_htm_log_pins_at_2p27(ctx):
     R = hj.generate_data("local_shuffle", n, n, 1024)
     S = hj.generate_data("sorted", n)
     got = ctx.run("htm", R, S)
-    # (a shuffle window of 1024 is more than the 8 KiB rings hold at 4 slots per 3 keys: the pre-round takes global atomics)
+    # (a shuffle window of 1024 is more than the 8 KiB rings hold at 4 slots per 3 keys: the pre-round takes the workgroup window)
     assert (got["conflicts"], got["totalMatches"], got["inputSum"], got["outputSum"], got["htmOverflowBuckets"], got["buildVariant"]) == (
-        0, n, 9007199321849856, 9007199321849856, 0, 1)
+        0, n, 9007199321849856, 9007199321849856, 0, 2)
     R = hj.generate_data("uniform", n, n, 16)                                   # duplicates at full size: the order-independent count
     got = ctx.run("htm", R, S)
     assert got["buildVariant"] == 3                                             # the reference's default window: the LDS rings
@@ -353,7 +357,7 @@ def test_mc_workloads_true_cardinality_on_both_join_paths(ctx, golden_dir):
                 ctx.run("htm", R, S)
             assert e.value.status == _lib.HJ_ERR_KEY_RANGE
             R, S = R + np.uint64(1), S + np.uint64(1)
-        for variant in (1, 3):
+        for variant in (1, 2, 3):
             got = ctx.run("htm", R, S, buildVariant=variant)
             assert got["totalMatches"] == row["results"], ("htm", variant, row)
             assert got["outputSum"] == got["inputSum"] == int(R.sum())
@@ -545,7 +549,7 @@ def test_config2_size_properties(ctx):
         c.probe_keys(dS + 8, n)
         c.checksums()
         k = c.fetch()
-        assert k["buildVariant"] == 4 and k["compactFallback"] == 0
+        assert k["buildVariant"] == 3 and k["compactFallback"] == 0          # duplicate keys: the classic rings
         for f in ("conflicts", "totalMatches", "inputSum", "tableSumFull", "conflictSum"):
             assert k[f] == got[f], f
         c.dev_free(dR); c.dev_free(dS)
