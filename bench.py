@@ -250,7 +250,19 @@ def cpu_baseline(hj, log2n, dist, window, R=None):
         us = r["build_us"] + r["probe_us"]
         best = us if best is None else min(best, us)
     rn = oracle.build_probe_mt(R, S, 4, 64, threads, atomic=False)
+    # the same loops on unique keys (what the reference's sweep runs, and what tools/sweep.py's CPU legs time): no retries,
+    # no failed CAS -- several times the rate of the duplicate-heavy `uniform`; measured at 2^27 so that it costs a blink.
+    # (Round 2 read this difference as a slowdown with size: the rate on `uniform` is 2.8-3.0 Gtuples/s at every size from
+    # 2^26 to 2^30, first-touched by the caller or by the worker threads alike -- tools/dbg/cpu_baseline_sizes.py.)
+    nu = 1 << min(27, log2n)
+    Ru = hj.generate_data("local_shuffle", nu, nu, 16)
+    Su = np.arange(1, nu + 1, dtype=np.uint64)
+    ru = min((oracle.build_probe_mt(Ru, Su, 4, 64, threads, atomic=True) for _ in range(2)), key=lambda r_: r_["build_us"] + r_["probe_us"])
+    unique_rate = 2 * nu / (ru["build_us"] + ru["probe_us"])
+    del Ru, Su
     return {
+        "unique_keys_sample": {"value": unique_rate, "unit": "Mtuples/s",
+                               "sample": f"the same CAS loops on local_shuffle W=16 (unique keys), |R|=|S|=2^{nu.bit_length() - 1}, best of 2"},
         "value": 2 * n / best, "unit": "Mtuples/s", "cores": threads, "kind": "port",
         "sample": f"atomic (CAS) build+probe on the relation the GPU leg joined, {dist} W={window}, |R|=|S|=2^{log2n}, "
                   f"best of 3, {threads} threads on {cores} effective CPUs (affinity + cgroup quota; os.cpu_count() = "

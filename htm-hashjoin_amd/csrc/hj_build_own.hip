@@ -620,13 +620,23 @@ k_sample_locality(const void* __restrict__ Rv, uint64_t n, uint64_t mask, uint32
         // variant 3: wavefront tiles of kWvTileTuples consecutive tuples; the ring of kWvRingGran granules ends just
         // above the tile's highest home granule but never starts above its lowest (k_build_wave's rule); each of this
         // block's wavefronts takes every fourth tile
-        uint32_t outsideWave = 0;
+        uint32_t outsideWave = 0, farRows = 0;
         for (uint64_t sb = b + (uint64_t)wave * kWvTileTuples; sb < e; sb += (uint64_t)(kBlock / 64) * kWvTileTuples) {
             const uint64_t se = sb + kWvTileTuples < e ? sb + kWvTileTuples : e;
             uint32_t glo = 0xFFFFFFFFu, ghiInv = 0xFFFFFFFFu;
+            // out[4]: rows of 64 consecutive tuples whose highest home slot lies above the lowest one of the row TWO rows
+            // later -- disorder that reaches further than 64 positions, which is as far as the compact ring build's seam
+            // zones reach (hj_build_wave.hip); the classic rings defer such stragglers, the compact ones would have to give up
+            uint32_t prevMax2 = 0, prevMax1 = 0;                       // highest home slot of the rows two / one before (wave-uniform)
             for (uint64_t i = sb + lane; i < se; i += 64) {
-                const uint32_t g = (home32<HTM>((uint32_t)R[i], hshift, (uint32_t)mask) >> kWvGranShift);
+                const uint32_t h = home32<HTM>((uint32_t)R[i], hshift, (uint32_t)mask);
+                const uint32_t g = h >> kWvGranShift;
                 glo = g < glo ? g : glo; ghiInv = ~g < ghiInv ? ~g : ghiInv;
+                if (se - sb == kWvTileTuples) {                          // whole rows only (all 64 lanes take part in the reductions)
+                    const uint32_t rowMin = wave_min_u32(h), rowMax = ~wave_min_u32(~h);
+                    farRows += (i >= sb + 128 + lane && prevMax2 > rowMin && lane == 0) ? 1u : 0u;
+                    prevMax2 = prevMax1; prevMax1 = rowMax;
+                }
             }
             glo = wave_min_u32(glo);
             const uint32_t top = ~wave_min_u32(ghiInv) + 1;
@@ -643,6 +653,7 @@ k_sample_locality(const void* __restrict__ Rv, uint64_t n, uint64_t mask, uint32
             outsideWave += __shfl_down(outsideWave, off, 64);
             dup += __shfl_down(dup, off, 64);
         }
+        if (lane == 0 && farRows) atomicAdd(&out[4], farRows);
         if (lane == 0 && outside) atomicAdd(&sOutside, outside);
         if (lane == 0 && outsideWave) atomicAdd(&sOutsideWave, outsideWave);
         if (lane == 0 && dup) atomicAdd(&sDup, dup);
@@ -660,7 +671,7 @@ bool own_supported(uint64_t tableSize) { return tableSize >= (uint64_t)kWinSlots
 hipError_t launch_sample_locality(const void* R, bool key32, uint64_t n, uint64_t tableSize, uint32_t hshift, uint32_t nSample,
                                   unsigned int* fitCount, hipStream_t s, bool htm)
 {
-    const hipError_t e = hipMemsetAsync(fitCount, 0, 4 * sizeof(unsigned int), s);
+    const hipError_t e = hipMemsetAsync(fitCount, 0, 8 * sizeof(unsigned int), s);
     if (e != hipSuccess) return e;
     if (htm)        // the bucketised table's own hash ((key / 3) << 2: the keys spread 4/3 as wide as in the open-addressing table)
         hipLaunchKernelGGL((k_sample_locality<false, true>), dim3(nSample < 256 ? nSample : 256), dim3(kBlock), 0, s,
@@ -771,14 +782,20 @@ void launch_build_deferred(const void* queueBuf, const unsigned long long* queue
                        nullptr, nullptr);
 }
 
-__global__ void k_pick_variant(const unsigned int* __restrict__ fit, bool canOwn, bool canWave, bool canCompact, Counters* __restrict__ ctr)
+__global__ void k_pick_variant(const unsigned int* __restrict__ fit, bool canOwn, bool canWave, bool canCompact, uint32_t allowedMask,
+                               Counters* __restrict__ ctr)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) ctr->variant = variant_for_sample(fit[0], fit[1], fit[2], canOwn, canWave, canCompact, fit[3]);
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const uint32_t pref = variant_for_sample(fit[0], fit[1], fit[2], canOwn, canWave, canCompact, fit[3], fit[4]);
+        ctr->preferred = pref;
+        ctr->variant = variant_among_allowed(pref, allowedMask);
+    }
 }
 
-void launch_pick_variant(const unsigned int* fitCount, bool canOwn, bool canWave, Counters* ctr, hipStream_t s, bool canCompact)
+void launch_pick_variant(const unsigned int* fitCount, bool canOwn, bool canWave, Counters* ctr, hipStream_t s, bool canCompact,
+                         uint32_t allowedMask)
 {
-    hipLaunchKernelGGL(k_pick_variant, dim3(1), dim3(64), 0, s, fitCount, canOwn, canWave, canCompact, ctr);
+    hipLaunchKernelGGL(k_pick_variant, dim3(1), dim3(64), 0, s, fitCount, canOwn, canWave, canCompact, allowedMask, ctr);
 }
 
 }  // namespace hj

@@ -629,6 +629,10 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
         }
 #endif
         // wave-uniform: no shadow / head zone, no overlap zone (COMPACT: and no tail zone)
+        if constexpr (COMPACT) {
+            // somebody has raised the flag: nothing written from here on is ever looked at (every 8th tile: one scalar load)
+            if ((tb & (8u * kWvTile - 1u)) == 7u * kWvTile && *reinterpret_cast<volatile unsigned long long*>(&ctr->compactFail)) return;
+        }
         const bool full = (tb + kWvTile <= (cend < tailFrom ? cend : tailFrom)) & (tb >= S + kWvOverlap);
         issue(nxt[p], tb + kWvPf * kWvTile);
         const uint32_t roundsAtTileStart = rounds;

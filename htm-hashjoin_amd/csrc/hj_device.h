@@ -81,6 +81,11 @@ struct Counters {
     // Build kernel the device-side locality pre-round picked (hj_params.buildVariant 0): written by k_pick_variant,
     // read through the Gate of every build kernel enqueued behind it, reported as hj_result.buildVariant
     unsigned long long variant;
+    // what the pre-round would have picked had every variant been enqueued (k_pick_variant). hj_build_dev only enqueues
+    // the kernels of the variant the PREVIOUS build of the context preferred (+ the classic rings behind the compact
+    // ones, + global atomics: always correct); the pick is taken among those, and this word tells the host what to
+    // enqueue next time (copied to pinned memory behind the pick, read without waiting at the next build)
+    unsigned long long preferred;
     // --algo htm (hj_htm.hip): overflow buckets linked, sum of the tuples they hold
     unsigned long long htmOverflowBuckets, htmOverflowSum;
     // PRJ, histogram-free partitioning (hj_prj.hip): set to 1 by the scatter kernel that finds a fragment too small;
@@ -149,7 +154,8 @@ struct KernelEvents { hipEvent_t before, after; };
 // ---- launch wrappers (defined in hj_kernels.hip) ---------------------------
 // Inputs come in two element formats: 8-byte DataGen tuples (key32 = false; value = key, payload bits must be 0)
 // or bare 32-bit keys (key32 = true; what the multi-GPU exchange delivers). Index of element i = idxBase + i.
-void launch_fill_empty(uint64_t* table, uint64_t nSlots, Gate gate, hipStream_t s);
+// fullRange != nullptr: also marks the whole table valid (variant 1 clears and may touch all of it): one launch less
+void launch_fill_empty(uint64_t* table, uint64_t nSlots, Gate gate, hipStream_t s, Counters* fullRange = nullptr, uint64_t tableSize = 0);
 void launch_build_atomic_min(const void* R, bool key32, uint64_t n, uint64_t* table, uint64_t tableSize, uint32_t hshift,
                              uint32_t probeLen, uint64_t idxBase, ShardCheck sc, Counters* ctr, Gate gate, hipStream_t s);
 // the probe and the checksums read Counters::tableFormat on the device: either table format, one launch
@@ -173,21 +179,33 @@ size_t own_queue_bytes(uint64_t rSize);
 size_t own_owner_bytes(uint64_t tableSize);
 bool   own_supported(uint64_t tableSize);
 // fitCount[0] = sampled tuples outside variant 2's window, [1] = tuples sampled, [2] = outside variant 3's ring,
-// [3] = sampled tuples that share their home slot with another tuple of their tile (duplicate keys)
+// [3] = sampled tuples that share their home slot with another tuple of their tile (duplicate keys),
+// [4] = sampled rows of 64 tuples with disorder beyond 64 positions (8 words in all)
 hipError_t launch_sample_locality(const void* R, bool key32, uint64_t n, uint64_t tableSize, uint32_t hshift, uint32_t nSample,
                                   unsigned int* fitCount, hipStream_t s, bool htm = false);   // htm: the bucketised table's hash
 // the pre-round's decision on the device: ctr->variant = 3 / 2 / 1 by the same thresholds the host applies
 // (sample_thresholds below); canOwn / canWave: which variants have their buffers
-void launch_pick_variant(const unsigned int* fitCount, bool canOwn, bool canWave, Counters* ctr, hipStream_t s, bool canCompact = false);
+// allowedMask: bit v set = the kernels of variant v are enqueued behind the pick (bit 1, global atomics, always is)
+void launch_pick_variant(const unsigned int* fitCount, bool canOwn, bool canWave, Counters* ctr, hipStream_t s, bool canCompact = false,
+                         uint32_t allowedMask = 0x1E);
+// the best enqueued variant for a preferred one: itself if enqueued, else the next looser build that is
+__host__ __device__ inline uint32_t variant_among_allowed(uint32_t preferred, uint32_t allowedMask)
+{
+    for (uint32_t v = preferred; v > 1; --v)
+        if ((allowedMask >> v) & 1u) return v == 3 && preferred == 2 ? 1u : v;       // (never the rings for loose locality)
+    return 1u;
+}
 // variant worth taking for a sample (outside variant 2's window, tuples seen, outside variant 3's ring)
 // dup = sampled tuples that share their home slot with another tuple of their tile: rings with few duplicate keys take the
 // compact table (4: 2.6 against 3.4 ms build at 2^30 on unique keys, and a 4-byte probe), rings with many keep the classic
 // one (3): on `uniform` (37 % of the tuples repeat a key) the build is bound by the vector work of its retry rounds, the
 // compact build adds forced rounds to it (4.0 against 3.6 ms) and the whole step comes out even.
 __host__ __device__ inline uint32_t variant_for_sample(uint64_t outOwn, uint64_t seen, uint64_t outWave, bool canOwn, bool canWave,
-                                                      bool canCompact = false, uint64_t dup = 0)
+                                                      bool canCompact = false, uint64_t dup = 0, uint64_t farRows = 0)
 {
-    if (canWave && outWave * 128 <= seen) return (canCompact && dup * 8 <= seen) ? 4 : 3;
+    // farRows: sampled rows of 64 tuples that reach above the row two further on (disorder beyond 64 positions: more than
+    // the compact build's seam zones cover -- it would start, give up and hand over to the classic rings)
+    if (canWave && outWave * 128 <= seen) return (canCompact && dup * 8 <= seen && farRows == 0) ? 4 : 3;
     if (canOwn && outOwn * 12 <= seen) return 2;
     return 1;
 }

@@ -54,9 +54,11 @@ static inline unsigned grid_for(uint64_t items, unsigned perBlock)
 // ---------------------------------------------------------------------------
 // table clear: 16-byte stores of the empty pattern
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_fill_empty(uint64_t* __restrict__ table, uint64_t nSlots, Gate gate)
+__global__ void __launch_bounds__(kBlock) k_fill_empty(uint64_t* __restrict__ table, uint64_t nSlots, Gate gate,
+                                                       Counters* __restrict__ fullRange, uint64_t tableSize)
 {
     if (gate_closed(gate)) return;
+    if (fullRange && blockIdx.x == 0 && threadIdx.x == 0) { fullRange->validLo = 0; fullRange->validHiEx = tableSize; }
     // table is hipMalloc'ed (256-B aligned); nSlots is even by construction
     ulonglong2* t2 = reinterpret_cast<ulonglong2*>(table);
     const uint64_t nv = nSlots >> 1;
@@ -66,9 +68,9 @@ __global__ void __launch_bounds__(kBlock) k_fill_empty(uint64_t* __restrict__ ta
     if (blockIdx.x == 0 && threadIdx.x == 0 && (nSlots & 1)) table[nSlots - 1] = kEmpty;
 }
 
-void launch_fill_empty(uint64_t* table, uint64_t nSlots, Gate gate, hipStream_t s)
+void launch_fill_empty(uint64_t* table, uint64_t nSlots, Gate gate, hipStream_t s, Counters* fullRange, uint64_t tableSize)
 {
-    hipLaunchKernelGGL(k_fill_empty, dim3(grid_for(nSlots / 2, kBlock * 4)), dim3(kBlock), 0, s, table, nSlots, gate);
+    hipLaunchKernelGGL(k_fill_empty, dim3(grid_for(nSlots / 2, kBlock * 4)), dim3(kBlock), 0, s, table, nSlots, gate, fullRange, tableSize);
 }
 
 // ---------------------------------------------------------------------------
