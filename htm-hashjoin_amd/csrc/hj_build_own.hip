@@ -54,15 +54,7 @@ constexpr uint32_t kWinBlocks = 16;
 constexpr uint32_t kWinSlots = kBlkSlots * kWinBlocks;   // 8192 slots = 64 KiB
 constexpr uint32_t kBackBlocks = 2;              // window keeps this much room behind a tile's lowest key
 
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const uint32_t o = __shfl_xor(v, off, 64);
-        v = o < v ? o : v;
-    }
-    return v;
-}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) { return wave_umin(v); }      // DPP steps (hj_device.h), not LDS permutes
 
 __device__ __forceinline__ uint64_t pack64(uint32_t hi, uint32_t lo) { return ((uint64_t)hi << 32) | lo; }
 
@@ -114,7 +106,7 @@ __global__ void __launch_bounds__(kOwnThreads, 4)
 k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
             uint64_t* __restrict__ table, uint64_t mask, uint32_t hshift, uint32_t probeLen, uint64_t idxBase, ShardCheck sc,
             unsigned int* __restrict__ owner, DeferredEntry* __restrict__ queue,
-            unsigned long long* __restrict__ queueCount, Counters* __restrict__ ctr, Gate gate,
+            uint32_t* __restrict__ deferCounts, Counters* __restrict__ ctr, Gate gate,
             uint64_t* __restrict__ htmConflicts, uint32_t* __restrict__ ccounts, uint32_t confSlice)
 {
     if (gate_closed(gate)) return;
@@ -123,6 +115,7 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
     __shared__ unsigned int need[kWinBlocks];    // per ring block: wanted by the current tile (count, or 0x10000 = unconditional)
     __shared__ unsigned int sTileMin;
     __shared__ unsigned int sConf;               // HTM: conflicts this workgroup has listed so far
+    __shared__ unsigned int sDefer;              // tuples this workgroup has deferred so far (entries of its queue slice)
     __shared__ uint32_t qPos[kOwnThreads / 64][kQCap], qLo[kOwnThreads / 64][kQCap], qHi[kOwnThreads / 64][kQCap];
 
     const uint64_t cb = (uint64_t)blockIdx.x * chunkLen;
@@ -140,8 +133,13 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
 
     for (uint32_t i = threadIdx.x; i < kWinSlots; i += kOwnThreads) win[i] = kEmpty;
     if (threadIdx.x < kWinBlocks) { owned[threadIdx.x] = 0; need[threadIdx.x] = 0; }
-    if (threadIdx.x == 0) { sTileMin = 0xFFFFFFFFu; sConf = 0; }
+    if (threadIdx.x == 0) { sTileMin = 0xFFFFFFFFu; sConf = 0; sDefer = 0; }
     __syncthreads();
+    // The deferred queue is sliced like R: this workgroup's entries go to queue[cb ..), at most one per tuple of its
+    // chunk, counted in LDS. (One global counter for all workgroups -- a returning atomic on ONE address per retry round
+    // that defers anything -- was what loose locality paid for: 3.5 ms of a 4.4 ms phase A on the bucketised table at
+    // 2^27, W = 1024, for 4.8 % of the tuples deferred.)
+    DeferredEntry* const myQueue = queue + cb;
     uint64_t* const myConflicts = HTM ? htmConflicts + (uint64_t)blockIdx.x * confSlice : nullptr;
     (void)myConflicts;
 
@@ -198,12 +196,12 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
         // deferred tuples leave for the global queue (one returning atomic per round that has any)
         const unsigned long long dm = __ballot(toDefer);
         if (dm) {
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(queueCount, (unsigned long long)__popcll(dm));
-            base = __shfl(base, 0, 64);
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(&sDefer, (unsigned int)__popcll(dm));
+            base = (unsigned int)__shfl((int)base, 0, 64);
             if (toDefer) {
-                const unsigned long long at = base + lane_rank(dm);
-                queue[at].pos = pos; queue[at].packed = mine;
+                const uint32_t at = base + lane_rank(dm);
+                myQueue[at].pos = pos; myQueue[at].packed = mine;
                 deferred += 1;
                 const uint32_t db = pos >> kBlkShift;
                 usedLo = db < usedLo ? db : usedLo; usedHi1 = db + 1 > usedHi1 ? db + 1 : usedHi1;
@@ -427,9 +425,10 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
             }
         }
     }
-    if constexpr (HTM) {
-        __syncthreads();
-        if (threadIdx.x == 0) ccounts[blockIdx.x] = sConf;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        deferCounts[blockIdx.x] = sDefer;
+        if constexpr (HTM) ccounts[blockIdx.x] = sConf;
     }
     // counters: one atomic per wavefront
     unsigned long long c0 = drops, c3 = bad | ((unsigned long long)foreign << 32), c4 = deferred;
@@ -522,16 +521,19 @@ k_clear_unowned(uint64_t* __restrict__ table, const unsigned int* __restrict__ o
 // deferred), reserved with one atomic per wavefront.
 template <bool HTM>
 __global__ void __launch_bounds__(kBlock)
-k_build_deferred(const DeferredEntry* __restrict__ queue, const unsigned long long* __restrict__ queueCount,
+k_build_deferred(const DeferredEntry* __restrict__ queueAll, const uint32_t* __restrict__ deferCounts, uint32_t sliceLen, uint32_t parts,
                  uint64_t* __restrict__ table, uint64_t mask, uint32_t hshift, uint32_t probeLen,
                  Counters* __restrict__ ctr, Gate gate, uint64_t* __restrict__ lastSlice, uint32_t* __restrict__ lastCount)
 {
     if (gate_closed(gate)) return;
-    const unsigned long long nq = *queueCount;
+    // slice c = blockIdx.x / parts (the entries workgroup c of phase A deferred), `parts` workgroups share it
+    const uint32_t c = blockIdx.x / parts, part = blockIdx.x - c * parts;
+    const DeferredEntry* __restrict__ queue = queueAll + (uint64_t)c * sliceLen;
+    const unsigned long long nq = deferCounts[c];
     unsigned long long drops = 0, dropSum = 0;
     const unsigned long long nqUp = (nq + 63ull) & ~63ull;                  // whole wavefronts stay in the loop (ballots below)
-    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < nqUp;
-         i += (unsigned long long)gridDim.x * kBlock) {
+    for (unsigned long long i = (unsigned long long)part * kBlock + threadIdx.x; i < nqUp;
+         i += (unsigned long long)parts * kBlock) {
         const bool has = i < nq;
         uint64_t mine = has ? queue[i].packed : 0;
         uint64_t pos = has ? queue[i].pos : 0;
@@ -583,23 +585,41 @@ k_build_deferred(const DeferredEntry* __restrict__ queue, const unsigned long lo
 template <bool KEY32, bool HTM = false>
 __global__ void __launch_bounds__(kBlock)
 k_sample_locality(const void* __restrict__ Rv, uint64_t n, uint64_t mask, uint32_t hshift, uint32_t nSample,
-                  unsigned int* __restrict__ out)
+                  unsigned int* __restrict__ out, SamplePick pick)
 {
     using Elem = typename std::conditional<KEY32, uint32_t, uint64_t>::type;
     const Elem* __restrict__ R = static_cast<const Elem*>(Rv);
-    __shared__ unsigned int sMinBlk, sOutside, sOutsideWave, sDup;
+    __shared__ unsigned int sMinBlk, sOutside, sOutsideWave, sDup, sFar, sLast;
     __shared__ unsigned int seen[(2 * kOwnTile) / 32];               // one bit per home slot of a tile's neighbourhood
     const uint64_t tiles = (n + kOwnTile - 1) / kOwnTile;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned int tot[5] = {0, 0, 0, 0, 0};                             // thread 0: this workgroup's five counts
     for (uint32_t s = blockIdx.x; s < nSample; s += gridDim.x) {
         const uint64_t tile = (tiles * s) / nSample;
         const uint64_t b = tile * kOwnTile, e = (b + kOwnTile < n) ? b + kOwnTile : n;
-        if (threadIdx.x == 0) { sMinBlk = 0xFFFFFFFFu; sOutside = 0; sOutsideWave = 0; sDup = 0; }
+        if (threadIdx.x == 0) { sMinBlk = 0xFFFFFFFFu; sOutside = 0; sOutsideWave = 0; sDup = 0; sFar = 0; }
         for (uint32_t i = threadIdx.x; i < (2 * kOwnTile) / 32; i += kBlock) seen[i] = 0;
         __syncthreads();
+        // The tile is read ONCE, sixteen independent loads per thread, and everything below works on the home slots in
+        // registers (three dependent sweeps over the tile -- min, window test, ring test -- were 33 us of latency per
+        // build whatever the size: most of a small relation's launch tail). Thread (wave w, lane l) holds, for k = 0, 1 and
+        // r = 0..7, tuple b + (4 k + w) * 512 + 64 r + l: wavefront w's two ring tiles of 512 consecutive tuples (what
+        // k_build_wave's wavefronts take), row r of 64 tuples in lane order.
+        static_assert(kOwnTile == 2 * (kBlock / 64) * (int)kWvTileTuples && kWvTileTuples == 8 * 64, "sample layout: 2 ring tiles of 8 rows per wavefront");
+        uint32_t h[16];
+        uint32_t okBits = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint64_t i = b + (uint64_t)((q >> 3) * (kBlock / 64) + wave) * kWvTileTuples + (uint32_t)(q & 7) * 64u + lane;
+            const bool ok = i < e;
+            h[q] = (uint32_t)R[ok ? i : b];
+            okBits |= (ok ? 1u : 0u) << q;
+        }
         uint32_t lo = 0xFFFFFFFFu;
-        for (uint64_t i = b + threadIdx.x; i < e; i += kBlock) {
-            const uint32_t hb = (home32<HTM>((uint32_t)R[i], hshift, (uint32_t)mask) >> kBlkShift);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            h[q] = home32<HTM>(h[q], hshift, (uint32_t)mask);
+            const uint32_t hb = ((okBits >> q) & 1u) ? h[q] >> kBlkShift : 0xFFFFFFFFu;
             lo = hb < lo ? hb : lo;
         }
         lo = wave_min_u32(lo);
@@ -607,34 +627,40 @@ k_sample_locality(const void* __restrict__ Rv, uint64_t n, uint64_t mask, uint32
         __syncthreads();
         const uint32_t wbase = sMinBlk > kBackBlocks ? sMinBlk - kBackBlocks : 0;
         uint32_t outside = 0, dup = 0;
-        for (uint64_t i = b + threadIdx.x; i < e; i += kBlock) {      // second sweep hits L2
-            const uint32_t h = home32<HTM>((uint32_t)R[i], hshift, (uint32_t)mask);
-            const uint32_t hb = h >> kBlkShift;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            if (!((okBits >> q) & 1u)) continue;
+            const uint32_t hb = h[q] >> kBlkShift;
             outside += (hb - wbase >= kWinBlocks) ? 1u : 0u;
             // tuples whose home slot another tuple of the tile has too (out[3]): with tight locality a tile's home slots lie
             // within about its own length, so one bit per slot of twice that tells -- the share of duplicate keys, which
             // decides between the two ring builds (the compact table's forced rounds only pay where retry rounds are few)
-            const uint32_t d = (h - (sMinBlk << kBlkShift)) & (2 * kOwnTile - 1);
+            const uint32_t d = (h[q] - (sMinBlk << kBlkShift)) & (2 * kOwnTile - 1);
             dup += (atomicOr(&seen[d >> 5], 1u << (d & 31)) >> (d & 31)) & 1u;
         }
         // variant 3: wavefront tiles of kWvTileTuples consecutive tuples; the ring of kWvRingGran granules ends just
-        // above the tile's highest home granule but never starts above its lowest (k_build_wave's rule); each of this
-        // block's wavefronts takes every fourth tile
+        // above the tile's highest home granule but never starts above its lowest (k_build_wave's rule)
         uint32_t outsideWave = 0, farRows = 0;
-        for (uint64_t sb = b + (uint64_t)wave * kWvTileTuples; sb < e; sb += (uint64_t)(kBlock / 64) * kWvTileTuples) {
-            const uint64_t se = sb + kWvTileTuples < e ? sb + kWvTileTuples : e;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const uint64_t sb = b + (uint64_t)(k * (kBlock / 64) + wave) * kWvTileTuples;
+            if (sb >= e) continue;                                       // wave-uniform
+            const bool whole = sb + kWvTileTuples <= e;
             uint32_t glo = 0xFFFFFFFFu, ghiInv = 0xFFFFFFFFu;
             // out[4]: rows of 64 consecutive tuples whose highest home slot lies above the lowest one of the row TWO rows
             // later -- disorder that reaches further than 64 positions, which is as far as the compact ring build's seam
             // zones reach (hj_build_wave.hip); the classic rings defer such stragglers, the compact ones would have to give up
             uint32_t prevMax2 = 0, prevMax1 = 0;                       // highest home slot of the rows two / one before (wave-uniform)
-            for (uint64_t i = sb + lane; i < se; i += 64) {
-                const uint32_t h = home32<HTM>((uint32_t)R[i], hshift, (uint32_t)mask);
-                const uint32_t g = h >> kWvGranShift;
-                glo = g < glo ? g : glo; ghiInv = ~g < ghiInv ? ~g : ghiInv;
-                if (se - sb == kWvTileTuples) {                          // whole rows only (all 64 lanes take part in the reductions)
-                    const uint32_t rowMin = wave_min_u32(h), rowMax = ~wave_min_u32(~h);
-                    farRows += (i >= sb + 128 + lane && prevMax2 > rowMin && lane == 0) ? 1u : 0u;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int q = k * 8 + r;
+                if ((okBits >> q) & 1u) {
+                    const uint32_t g = h[q] >> kWvGranShift;
+                    glo = g < glo ? g : glo; ghiInv = ~g < ghiInv ? ~g : ghiInv;
+                }
+                if (whole) {                                             // whole rows only (all 64 lanes take part in the reductions)
+                    const uint32_t rowMin = wave_min_u32(h[q]), rowMax = ~wave_min_u32(~h[q]);
+                    farRows += (r >= 2 && prevMax2 > rowMin && lane == 0) ? 1u : 0u;
                     prevMax2 = prevMax1; prevMax1 = rowMax;
                 }
             }
@@ -642,9 +668,11 @@ k_sample_locality(const void* __restrict__ Rv, uint64_t n, uint64_t mask, uint32
             const uint32_t top = ~wave_min_u32(ghiInv) + 1;
             uint32_t gbase = top > kWvRingGran ? top - kWvRingGran : 0;
             gbase = gbase < glo ? gbase : glo;
-            for (uint64_t i = sb + lane; i < se; i += 64) {
-                const uint32_t g = (home32<HTM>((uint32_t)R[i], hshift, (uint32_t)mask) >> kWvGranShift);
-                outsideWave += (g - gbase >= kWvRingGran) ? 1u : 0u;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int q = k * 8 + r;
+                const uint32_t g = h[q] >> kWvGranShift;
+                outsideWave += (((okBits >> q) & 1u) && g - gbase >= kWvRingGran) ? 1u : 0u;
             }
         }
 #pragma unroll
@@ -653,13 +681,52 @@ k_sample_locality(const void* __restrict__ Rv, uint64_t n, uint64_t mask, uint32
             outsideWave += __shfl_down(outsideWave, off, 64);
             dup += __shfl_down(dup, off, 64);
         }
-        if (lane == 0 && farRows) atomicAdd(&out[4], farRows);
+        if (lane == 0 && farRows) atomicAdd(&sFar, farRows);
         if (lane == 0 && outside) atomicAdd(&sOutside, outside);
         if (lane == 0 && outsideWave) atomicAdd(&sOutsideWave, outsideWave);
         if (lane == 0 && dup) atomicAdd(&sDup, dup);
         __syncthreads();
-        if (threadIdx.x == 0) { atomicAdd(&out[0], sOutside); atomicAdd(&out[1], (unsigned int)(e - b)); atomicAdd(&out[2], sOutsideWave); atomicAdd(&out[3], sDup); }
+        if (threadIdx.x == 0) { tot[0] += sOutside; tot[1] += (unsigned int)(e - b); tot[2] += sOutsideWave; tot[3] += sDup; tot[4] += sFar; }
         __syncthreads();
+    }
+    // Totals without atomics on shared words (256 workgroups x 5 atomic adds on five addresses were served one after the
+    // other: half of this kernel's 25 us): every workgroup stores its five counts in a slot of its own, takes a ticket
+    // (out[7]), and the workgroup that finishes last adds the slots up -- and, for build_common's pre-round, picks on the
+    // device: it writes the variant word every build kernel enqueued behind this launch is gated on (no second launch),
+    // and what the sample PREFERS (whether or not its kernels were enqueued this time) goes straight into pinned host
+    // memory, where the next step's enqueue reads it without waiting: a store, not a copy in the stream.
+    unsigned int* const slots = out + 8;
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < 5; ++i) slots[8 * blockIdx.x + i] = tot[i];
+        __threadfence();
+        sLast = atomicAdd(&out[7], 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!sLast) return;
+    __threadfence();
+    unsigned int f[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        unsigned int v = 0;
+        for (uint32_t bk = threadIdx.x; bk < gridDim.x; bk += kBlock)
+            v += __hip_atomic_load(&slots[8 * bk + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        f[i] = v;
+    }
+    if (threadIdx.x == 0) { sOutside = 0; sOutsideWave = 0; sDup = 0; sFar = 0; sMinBlk = 0; }
+    __syncthreads();
+    if (lane == 0) { atomicAdd(&sOutside, f[0]); atomicAdd(&sMinBlk, f[1]); atomicAdd(&sOutsideWave, f[2]); atomicAdd(&sDup, f[3]); atomicAdd(&sFar, f[4]); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        f[0] = sOutside; f[1] = sMinBlk; f[2] = sOutsideWave; f[3] = sDup; f[4] = sFar;
+        for (int i = 0; i < 5; ++i) out[i] = f[i];
+        if (pick.ctr) {
+            const uint32_t pref = variant_for_sample(f[0], f[1], f[2], pick.canOwn, pick.canWave, pick.canCompact, f[3], f[4]);
+            pick.ctr->preferred = pref;
+            pick.ctr->variant = variant_among_allowed(pref, pick.allowedMask);
+            if (pick.hostPreferred) __hip_atomic_store(pick.hostPreferred, (unsigned long long)pref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -669,19 +736,21 @@ size_t own_owner_bytes(uint64_t tableSize) { return ((tableSize >> kBlkShift) + 
 bool own_supported(uint64_t tableSize) { return tableSize >= (uint64_t)kWinSlots; }
 
 hipError_t launch_sample_locality(const void* R, bool key32, uint64_t n, uint64_t tableSize, uint32_t hshift, uint32_t nSample,
-                                  unsigned int* fitCount, hipStream_t s, bool htm)
+                                  unsigned int* fitCount, hipStream_t s, bool htm, SamplePick pick, bool zeroed)
 {
-    const hipError_t e = hipMemsetAsync(fitCount, 0, 8 * sizeof(unsigned int), s);
-    if (e != hipSuccess) return e;
+    if (!zeroed) {      // the totals and the ticket (build_common keeps the words inside Counters: its one memset has cleared them already)
+        const hipError_t e = hipMemsetAsync(fitCount, 0, 8 * sizeof(unsigned int), s);
+        if (e != hipSuccess) return e;
+    }
     if (htm)        // the bucketised table's own hash ((key / 3) << 2: the keys spread 4/3 as wide as in the open-addressing table)
         hipLaunchKernelGGL((k_sample_locality<false, true>), dim3(nSample < 256 ? nSample : 256), dim3(kBlock), 0, s,
-                           R, n, tableSize - 1, hshift, nSample, fitCount);
+                           R, n, tableSize - 1, hshift, nSample, fitCount, pick);
     else if (key32)
         hipLaunchKernelGGL(k_sample_locality<true>, dim3(nSample < 256 ? nSample : 256), dim3(kBlock), 0, s,
-                           R, n, tableSize - 1, hshift, nSample, fitCount);
+                           R, n, tableSize - 1, hshift, nSample, fitCount, pick);
     else
         hipLaunchKernelGGL(k_sample_locality<false>, dim3(nSample < 256 ? nSample : 256), dim3(kBlock), 0, s,
-                           R, n, tableSize - 1, hshift, nSample, fitCount);
+                           R, n, tableSize - 1, hshift, nSample, fitCount, pick);
     return hipGetLastError();
 }
 
@@ -735,7 +804,7 @@ size_t own_conflict_count_bytes(uint64_t n, int nCU)
 
 hipError_t launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshift, uint64_t* table,
                             uint64_t tableSize, uint32_t probeLen, uint64_t idxBase, ShardCheck sc, int nCU, void* ownerBuf,
-                            void* queueBuf, unsigned long long* queueCount, Counters* ctr, Gate gate, int parts,
+                            void* queueBuf, uint32_t* deferCounts, Counters* ctr, Gate gate, int parts,
                             hipEvent_t evPhaseA, hipStream_t s, const KernelEvents* kev, uint64_t* htmConflicts, uint32_t* htmCounts)
 {
     const bool htm = htmConflicts != nullptr;
@@ -746,14 +815,14 @@ hipError_t launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshi
     hipError_t e;
     if (parts & 1) {
     if ((e = hipMemsetAsync(ownerBuf, 0, own_owner_bytes(tableSize), s)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(queueCount, 0, sizeof(unsigned long long), s)) != hipSuccess) return e;
+    if (nChunks > kOwnMaxChunks) return hipErrorInvalidValue;
     if (htm && (e = hipMemsetAsync(htmCounts, 0, own_conflict_count_bytes(n, nCU), s)) != hipSuccess) return e;
     const unsigned grid = (unsigned)nChunks;
     if (kev && (e = hipEventRecord(kev->before, s)) != hipSuccess) return e;
 #define HJ_OWN_LAUNCH(K32, CHK, HTM)                                                                                 \
     hipLaunchKernelGGL((k_build_own<K32, CHK, HTM>), dim3(grid), dim3(kOwnThreads), kWinSlots * sizeof(uint64_t), s,  \
                        R, n, chunkLen, table, tableSize - 1, hshift, probeLen, idxBase, sc,                            \
-                       static_cast<unsigned int*>(ownerBuf), static_cast<DeferredEntry*>(queueBuf), queueCount, ctr, gate, \
+                       static_cast<unsigned int*>(ownerBuf), static_cast<DeferredEntry*>(queueBuf), deferCounts, ctr, gate, \
                        htmConflicts, htmCounts, (uint32_t)chunkLen)
     if (htm) HJ_OWN_LAUNCH(false, false, true);
     else if (sc.mask) { if (key32) HJ_OWN_LAUNCH(true, true, false); else HJ_OWN_LAUNCH(false, true, false); }   // the instances that count foreign tuples
@@ -767,35 +836,17 @@ hipError_t launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshi
     hipLaunchKernelGGL(k_finalize_range, dim3(1), dim3(64), 0, s, ctr, numBlocks, tableSize, gate);
     hipLaunchKernelGGL(k_clear_unowned, dim3(2048), dim3(kBlock), 0, s, table,
                        static_cast<const unsigned int*>(ownerBuf), ctr, numBlocks, tableSize, gate);
+    // phase B: `parts` workgroups per slice (about 4096 in all: the walks are chains of dependent global atomics)
+    const uint32_t defParts = nChunks >= 4096 ? 1u : (uint32_t)(4096 / nChunks);
+    const dim3 gDef((unsigned)(nChunks * defParts));
     if (htm)
-        hipLaunchKernelGGL(k_build_deferred<true>, dim3(1024), dim3(kBlock), 0, s, static_cast<const DeferredEntry*>(queueBuf), queueCount,
-                           table, tableSize - 1, hshift, probeLen, ctr, gate, htmConflicts + nChunks * chunkLen, htmCounts + nChunks);
-    else launch_build_deferred(queueBuf, queueCount, table, tableSize, hshift, probeLen, ctr, gate, s);
+        hipLaunchKernelGGL(k_build_deferred<true>, gDef, dim3(kBlock), 0, s, static_cast<const DeferredEntry*>(queueBuf), deferCounts,
+                           (uint32_t)chunkLen, defParts, table, tableSize - 1, hshift, probeLen, ctr, gate, htmConflicts + nChunks * chunkLen,
+                           htmCounts + nChunks);
+    else
+        hipLaunchKernelGGL(k_build_deferred<false>, gDef, dim3(kBlock), 0, s, static_cast<const DeferredEntry*>(queueBuf), deferCounts,
+                           (uint32_t)chunkLen, defParts, table, tableSize - 1, hshift, probeLen, ctr, gate, nullptr, nullptr);
     return hipGetLastError();
-}
-
-void launch_build_deferred(const void* queueBuf, const unsigned long long* queueCount, uint64_t* table, uint64_t tableSize,
-                           uint32_t hshift, uint32_t probeLen, Counters* ctr, Gate gate, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_build_deferred<false>, dim3(1024), dim3(kBlock), 0, s,
-                       static_cast<const DeferredEntry*>(queueBuf), queueCount, table, tableSize - 1, hshift, probeLen, ctr, gate,
-                       nullptr, nullptr);
-}
-
-__global__ void k_pick_variant(const unsigned int* __restrict__ fit, bool canOwn, bool canWave, bool canCompact, uint32_t allowedMask,
-                               Counters* __restrict__ ctr)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const uint32_t pref = variant_for_sample(fit[0], fit[1], fit[2], canOwn, canWave, canCompact, fit[3], fit[4]);
-        ctr->preferred = pref;
-        ctr->variant = variant_among_allowed(pref, allowedMask);
-    }
-}
-
-void launch_pick_variant(const unsigned int* fitCount, bool canOwn, bool canWave, Counters* ctr, hipStream_t s, bool canCompact,
-                         uint32_t allowedMask)
-{
-    hipLaunchKernelGGL(k_pick_variant, dim3(1), dim3(64), 0, s, fitCount, canOwn, canWave, canCompact, allowedMask, ctr);
 }
 
 }  // namespace hj

@@ -114,25 +114,6 @@ __device__ __forceinline__ uint64_t wv_pack(uint32_t hi, uint32_t lo) { return (
 // ballot, ~50 per tile in a kernel whose retry rounds are bound by vector issue. This form takes the mask as it is.
 __device__ __forceinline__ unsigned long long wv_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
-// minimum over the wavefront, result wave-uniform: four DPP steps inside each row of 16, then the four rows
-__device__ __forceinline__ uint32_t wave_umin(uint32_t v)
-{
-    auto step = [](uint32_t x, const int ctrl) {
-        uint32_t o;
-        switch (ctrl) {     // the control word must be an immediate
-            case 0: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xF, 0xF, true); break;   // quad_perm [1,0,3,2]
-            case 1: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xF, 0xF, true); break;   // quad_perm [2,3,0,1]
-            case 2: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xF, 0xF, true); break;  // row_half_mirror
-            default: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xF, 0xF, true); break; // row_mirror
-        }
-        return o < x ? o : x;
-    };
-    v = step(v, 0); v = step(v, 1); v = step(v, 2); v = step(v, 3);
-    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
-    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
-    const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
-    return ab < cd ? ab : cd;
-}
 
 // ---- pre-pass: where every chunk starts and which slot range it owns -----------------------------------------------
 // Chunk c nominally starts at position p = c * chunkLen. The seam is moved to where the data crosses a granule
@@ -914,7 +895,8 @@ template <bool HTM>
 __global__ void __launch_bounds__(kBlock)
 k_wave_deferred(const DeferredEntry* __restrict__ queue, const uint32_t* __restrict__ dcounts, uint32_t nChunks,
                 uint32_t chunkLen, uint64_t* __restrict__ table, uint64_t mask, uint32_t hshift, uint32_t probeLen,
-                Counters* __restrict__ ctr, Gate gate, uint64_t* __restrict__ htmConflicts, uint32_t* __restrict__ ccounts)
+                Counters* __restrict__ ctr, Gate gate, uint64_t* __restrict__ htmConflicts, uint32_t* __restrict__ ccounts,
+                const uint32_t* __restrict__ routeBounds)
 {
     if (gate_closed(gate)) return;
     const uint32_t lane = threadIdx.x & 63;
@@ -947,6 +929,20 @@ k_wave_deferred(const DeferredEntry* __restrict__ queue, const uint32_t* __restr
             if constexpr (HTM) {
                 // the slice's conflict list is appended to by four wavefronts now: one atomic per wavefront reserves the places
                 // (ccounts[c] holds what k_build_wave recorded; the list's order is free, the chain phase sorts by index)
+                if (routeBounds) {
+                    // routed (hj_htm.hip, the chain phase in LDS): the conflict is filed under the chunk that OWNS its bucket's
+                    // granule -- the last chunk whose first granule is not above it --, so that a slice of the list holds all
+                    // conflicts of its chunk's range. A slice that cannot take it: the host redoes the build unrouted.
+                    if (dropped) {
+                        const uint32_t gran = (uint32_t)(home32<true>((uint32_t)mine, hshift, (uint32_t)mask) >> kGranShift);
+                        uint32_t a = 0, b = nChunks;                                   // bounds[a] <= gran (or a = 0), answer in [a, b)
+                        while (b - a > 1) { const uint32_t mid = (a + b) >> 1; if (routeBounds[mid] <= gran) a = mid; else b = mid; }
+                        const uint32_t at = atomicAdd(&ccounts[a], 1u);
+                        if (at < chunkLen) htmConflicts[(uint64_t)a * chunkLen + at] = mine;
+                        else atomicExch(&ctr->htmChainBail, 1ull);
+                    }
+                    continue;
+                }
                 const unsigned long long cm = wv_ballot(dropped);
                 if (cm) {
                     uint32_t base = 0;
@@ -970,43 +966,45 @@ k_wave_deferred(const DeferredEntry* __restrict__ queue, const uint32_t* __restr
 
 // After k_build_wave: the valid slot range (hj_device.h, Counters) = the owned stretch [ownLo, ownHiEx) joined
 // with the blocks deferred tuples start from (+1: a probe walk spills at most probeLen - 1 slots). If it reaches
-// the table's end (walks wrap there) the whole table is made valid.
-__global__ void k_wave_finalize_range(Counters* __restrict__ ctr, uint64_t tableSize, Gate gate)
-{
-    if (blockIdx.x != 0 || threadIdx.x >= 64 || gate_closed(gate)) return;
-    // the two maxima: what was written directly + the 64 shards (hj_device.h, Counters), one shard per lane
-    static_assert(Counters::kShards == 64, "one shard per lane of the single wavefront this kernel runs as");
-    unsigned long long usedLoInvAll = ctr->shard[threadIdx.x & 63].usedLoInv, usedHi1All = ctr->shard[threadIdx.x & 63].usedHi1;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long a = __shfl_xor(usedLoInvAll, off, 64), b = __shfl_xor(usedHi1All, off, 64);
-        usedLoInvAll = a > usedLoInvAll ? a : usedLoInvAll; usedHi1All = b > usedHi1All ? b : usedHi1All;
-    }
-    usedLoInvAll = ctr->usedLoInv > usedLoInvAll ? ctr->usedLoInv : usedLoInvAll;
-    usedHi1All = ctr->usedHi1 > usedHi1All ? ctr->usedHi1 : usedHi1All;
-    if (threadIdx.x != 0) return;
-    unsigned long long lo = ctr->ownLo, hiEx = ctr->ownHiEx;
-    const unsigned long long hi1 = usedHi1All;
-    if (hi1) {
-        const unsigned long long dlo = (unsigned long long)(uint32_t)~(uint32_t)usedLoInvAll << 9, dhi = (hi1 + 1) << 9;
-        lo = dlo < lo ? dlo : lo; hiEx = dhi > hiEx ? dhi : hiEx;
-    }
-    if (hiEx + 512 >= tableSize) { lo = 0; hiEx = tableSize; }
-    ctr->validLo = lo; ctr->validHiEx = hiEx;
-}
-
-// Slots of the valid range (+512 slots of defined contents past it, + the slack past the table) that no wavefront
-// owned: [validLo, ownLo) and [ownHiEx, validHiEx + 512).
+// the table's end (walks wrap there) the whole table is made valid. Then the slots of the valid range (+512 slots of
+// defined contents past it, + the slack past the table) that no wavefront owned, [validLo, ownLo) and
+// [ownHiEx, validHiEx + 512), are set to empty. One launch: every workgroup folds the 64 counter shards for itself
+// (one wavefront, 2 x 64 loads that hit L2), workgroup 0 publishes the range for the deferred phase and the probe.
 __global__ void __launch_bounds__(kBlock)
-k_wave_fill_edges(uint64_t* __restrict__ table, const Counters* __restrict__ ctr, uint64_t tableSize, Gate gate)
+k_wave_fill_edges(uint64_t* __restrict__ table, Counters* __restrict__ ctr, uint64_t tableSize, Gate gate)
 {
     if (gate_closed(gate)) return;
+    __shared__ unsigned long long sLo, sHiEx;
+    if (threadIdx.x < 64) {
+        // the two maxima: what was written directly + the 64 shards (hj_device.h, Counters), one shard per lane
+        static_assert(Counters::kShards == 64, "one shard per lane of the wavefront that folds them");
+        unsigned long long usedLoInvAll = ctr->shard[threadIdx.x].usedLoInv, usedHi1All = ctr->shard[threadIdx.x].usedHi1;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long a = __shfl_xor(usedLoInvAll, off, 64), b = __shfl_xor(usedHi1All, off, 64);
+            usedLoInvAll = a > usedLoInvAll ? a : usedLoInvAll; usedHi1All = b > usedHi1All ? b : usedHi1All;
+        }
+        usedLoInvAll = ctr->usedLoInv > usedLoInvAll ? ctr->usedLoInv : usedLoInvAll;
+        usedHi1All = ctr->usedHi1 > usedHi1All ? ctr->usedHi1 : usedHi1All;
+        if (threadIdx.x == 0) {
+            unsigned long long lo = ctr->ownLo, hiEx = ctr->ownHiEx;
+            const unsigned long long hi1 = usedHi1All;
+            if (hi1) {
+                const unsigned long long dlo = (unsigned long long)(uint32_t)~(uint32_t)usedLoInvAll << 9, dhi = (hi1 + 1) << 9;
+                lo = dlo < lo ? dlo : lo; hiEx = dhi > hiEx ? dhi : hiEx;
+            }
+            if (hiEx + 512 >= tableSize) { lo = 0; hiEx = tableSize; }
+            sLo = lo; sHiEx = hiEx;
+            if (blockIdx.x == 0) { ctr->validLo = lo; ctr->validHiEx = hiEx; }      // nobody in this launch reads them
+        }
+    }
+    __syncthreads();
     const ulonglong2 e = make_ulonglong2(kEmpty, kEmpty);
     ulonglong2* t2 = reinterpret_cast<ulonglong2*>(table);
     const uint64_t stride = (uint64_t)gridDim.x * kBlock, t0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    uint64_t hi = ctr->validHiEx + 512;
+    uint64_t hi = sHiEx + 512;
     hi = hi < tableSize ? hi : tableSize;
-    const uint64_t a0 = ctr->validLo >> 1, a1 = ctr->ownLo >> 1;          // all bounds are even (granules / blocks)
+    const uint64_t a0 = sLo >> 1, a1 = ctr->ownLo >> 1;                   // all bounds are even (granules / blocks)
     for (uint64_t v = a0 + t0; v < a1; v += stride) t2[v] = e;
     const uint64_t b0 = ctr->ownHiEx >> 1, b1 = hi >> 1;
     for (uint64_t v = b0 + t0; v < b1; v += stride) t2[v] = e;
@@ -1132,12 +1130,13 @@ WaveSlices wave_conflict_layout(uint64_t n, int nCU, void* boundsBuf)
     return WaveSlices{(uint32_t)((n + chunkLen - 1) / chunkLen), (uint32_t)wave_slice_len(chunkLen),
                       static_cast<const uint32_t*>(boundsBuf) + 4 * (size_t)maxChunks + 2};
 }
+const uint32_t* wave_bounds_ptr(int nCU, const void* boundsBuf) { return static_cast<const uint32_t*>(boundsBuf) + wave_max_chunks(nCU); }
 size_t wave_conflict_bytes(uint64_t n, int nCU) { return wave_queue_bytes(n, nCU) / sizeof(DeferredEntry) * sizeof(uint64_t); }
 
 hipError_t launch_build_wave(const void* R, bool key32, uint64_t n, uint32_t hshift, uint64_t* table, uint64_t tableSize,
                              uint32_t probeLen, uint64_t idxBase, ShardCheck sc, int nCU, void* boundsBuf, void* queueBuf,
                              Counters* ctr, Gate gate, int parts, hipEvent_t evPhaseA, hipStream_t s, uint64_t* htmConflicts,
-                             int mode, uint32_t fallbackVariant, const KernelEvents* kev)
+                             int mode, uint32_t fallbackVariant, const KernelEvents* kev, bool htmRoute)
 {
     const bool htm = htmConflicts != nullptr;
     const bool compact = mode == kWaveCompact;
@@ -1196,13 +1195,13 @@ hipError_t launch_build_wave(const void* R, bool key32, uint64_t n, uint32_t hsh
         hipLaunchKernelGGL(k_wave_fill_edges_keys, dim3(512), dim3(kBlock), 0, s, reinterpret_cast<uint32_t*>(table), ctr, tableSize, gate);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_wave_finalize_range, dim3(1), dim3(64), 0, s, ctr, tableSize, gate);
-    hipLaunchKernelGGL(k_wave_fill_edges, dim3(2048), dim3(kBlock), 0, s, table, ctr, tableSize, gate);
+    hipLaunchKernelGGL(k_wave_fill_edges, dim3(1024), dim3(kBlock), 0, s, table, ctr, tableSize, gate);
     const dim3 gDef(nChunks);                                  // one workgroup per slice
     if (htm) hipLaunchKernelGGL(k_wave_deferred<true>, gDef, dim3(kBlock), 0, s, static_cast<const DeferredEntry*>(queueBuf), dcounts,
-                                nChunks, sliceLen, table, tableSize - 1, hshift, probeLen, ctr, gate, htmConflicts, ccounts);
+                                nChunks, sliceLen, table, tableSize - 1, hshift, probeLen, ctr, gate, htmConflicts, ccounts,
+                                htmRoute ? bounds : nullptr);
     else hipLaunchKernelGGL(k_wave_deferred<false>, gDef, dim3(kBlock), 0, s, static_cast<const DeferredEntry*>(queueBuf), dcounts,
-                            nChunks, sliceLen, table, tableSize - 1, hshift, probeLen, ctr, gate, nullptr, nullptr);
+                            nChunks, sliceLen, table, tableSize - 1, hshift, probeLen, ctr, gate, nullptr, nullptr, nullptr);
     return hipGetLastError();
 }
 

@@ -54,6 +54,10 @@ __host__ __device__ inline bool is_foreign(uint32_t key, const ShardCheck& sc) {
 constexpr int kBlock = 256;          // 4 wavefronts of 64
 constexpr int kWave = 64;
 
+// words launch_sample_locality works on: 8 (five totals, [7] = the ticket) + 8 per workgroup of the sampler (its own counts)
+constexpr int kSampleBlocks = 256;
+constexpr int kSampleWords = 8 + 8 * kSampleBlocks;
+
 // Device-resident counters, zeroed at the start of a build. One cache line
 // apart is not needed: each is touched once per wavefront at kernel end.
 struct Counters {
@@ -78,16 +82,19 @@ struct Counters {
     unsigned long long foreign;      // tuples of the build / probe inputs that fail the shard check (ShardCheck)
     // Variant 3 (hj_build_wave.hip): the stretch of the table its wavefronts own and write whole, [ownLo, ownHiEx)
     unsigned long long ownLo, ownHiEx;
-    // Build kernel the device-side locality pre-round picked (hj_params.buildVariant 0): written by k_pick_variant,
+    // Build kernel the device-side locality pre-round picked (hj_params.buildVariant 0): written by the sampler's last workgroup (k_sample_locality),
     // read through the Gate of every build kernel enqueued behind it, reported as hj_result.buildVariant
     unsigned long long variant;
-    // what the pre-round would have picked had every variant been enqueued (k_pick_variant). hj_build_dev only enqueues
+    // what the pre-round would have picked had every variant been enqueued (k_sample_locality). hj_build_dev only enqueues
     // the kernels of the variant the PREVIOUS build of the context preferred (+ the classic rings behind the compact
     // ones, + global atomics: always correct); the pick is taken among those, and this word tells the host what to
-    // enqueue next time (copied to pinned memory behind the pick, read without waiting at the next build)
+    // enqueue next time (the kernel stores it into pinned host memory as well, read without waiting at the next build)
     unsigned long long preferred;
     // --algo htm (hj_htm.hip): overflow buckets linked, sum of the tuples they hold
     unsigned long long htmOverflowBuckets, htmOverflowSum;
+    // raised by the LDS chain phase (k_htm_chain_lds) or by the routing of the deferred phase's conflicts when an input
+    // does not fit them: the host then redoes the build without routing and chains with the generic kernels
+    unsigned long long htmChainBail;
     // PRJ, histogram-free partitioning (hj_prj.hip): set to 1 by the scatter kernel that finds a fragment too small;
     // the rest of that path then returns at once and the exact (histogram) path, gated on this word, runs instead
     unsigned long long prjFallback;
@@ -98,6 +105,9 @@ struct Counters {
     // k_table_sums and hj_export_table read the word. compactFail: raised by the compact build when it meets something
     // only the classic builds can handle; k_wave_decide then resets the counters and hands over to the classic build.
     unsigned long long tableFormat, compactFail;
+    // the locality pre-round's sample of hj_build_dev (k_sample_locality: launch_sample_locality's eight words, [7] = its
+    // ticket) -- inside this struct so that the one memset at the start of a build clears them too
+    unsigned int fit[kSampleWords];
     // The sums every wavefront contributes to at the END of a kernel (above: conflicts, conflictSum, inputSum, matches,
     // badKeys, prjMatches, prjChecksum, deferred, foreign, and the two maxima usedLoInv / usedHi1) are collected in 64
     // shards, each on a 128-byte line of its own, picked by wavefront number. Thousands of wavefronts finish together, and
@@ -112,6 +122,26 @@ struct Counters {
     static constexpr int kShards = 64;
     Shard shard[kShards];
 };
+
+// minimum over the wavefront, result wave-uniform: four DPP steps inside each row of 16, then the four rows
+__device__ __forceinline__ uint32_t wave_umin(uint32_t v)
+{
+    auto step = [](uint32_t x, const int ctrl) {
+        uint32_t o;
+        switch (ctrl) {     // the control word must be an immediate
+            case 0: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xF, 0xF, true); break;   // quad_perm [1,0,3,2]
+            case 1: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xF, 0xF, true); break;   // quad_perm [2,3,0,1]
+            case 2: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xF, 0xF, true); break;  // row_half_mirror
+            default: o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xF, 0xF, true); break; // row_mirror
+        }
+        return o < x ? o : x;
+    };
+    v = step(v, 0); v = step(v, 1); v = step(v, 2); v = step(v, 3);
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
 
 // the shard of the calling wavefront
 __device__ inline Counters::Shard* counter_shard(Counters* ctr)
@@ -181,19 +211,34 @@ bool   own_supported(uint64_t tableSize);
 // fitCount[0] = sampled tuples outside variant 2's window, [1] = tuples sampled, [2] = outside variant 3's ring,
 // [3] = sampled tuples that share their home slot with another tuple of their tile (duplicate keys),
 // [4] = sampled rows of 64 tuples with disorder beyond 64 positions (8 words in all)
+// pick.ctr != nullptr: the workgroup of the sample that finishes last decides on the device -- ctr->preferred = the variant
+// the sample asks for (variant_for_sample: the thresholds the host applies), ctr->variant = the best one among the
+// variants whose kernels are enqueued behind the sample (allowedMask: bit v set = variant v is; bit 1, global atomics,
+// always is), *hostPreferred (pinned host memory, may be null) = preferred, stored by the kernel itself.
+struct SamplePick {
+    Counters* ctr = nullptr;
+    unsigned long long* hostPreferred = nullptr;
+    uint32_t allowedMask = 0x1E;
+    bool canOwn = false, canWave = false, canCompact = false;
+};
+// zeroed: fitCount's eight words are zero already (no memset of its own)
 hipError_t launch_sample_locality(const void* R, bool key32, uint64_t n, uint64_t tableSize, uint32_t hshift, uint32_t nSample,
-                                  unsigned int* fitCount, hipStream_t s, bool htm = false);   // htm: the bucketised table's hash
-// the pre-round's decision on the device: ctr->variant = 3 / 2 / 1 by the same thresholds the host applies
-// (sample_thresholds below); canOwn / canWave: which variants have their buffers
-// allowedMask: bit v set = the kernels of variant v are enqueued behind the pick (bit 1, global atomics, always is)
-void launch_pick_variant(const unsigned int* fitCount, bool canOwn, bool canWave, Counters* ctr, hipStream_t s, bool canCompact = false,
-                         uint32_t allowedMask = 0x1E);
-// the best enqueued variant for a preferred one: itself if enqueued, else the next looser build that is
+                                  unsigned int* fitCount, hipStream_t s, bool htm = false,    // htm: the bucketised table's hash
+                                  SamplePick pick = SamplePick{}, bool zeroed = false);
+// the best enqueued variant for a preferred one: itself if enqueued, else the next looser build that is, else (nothing
+// looser is enqueued: a context whose relation lost its locality since the last build) the tightest LDS build that is --
+// rings and window are correct on any input (what falls outside goes through their deferred phases: global atomics,
+// slow for that one step); the compact rings only with the classic ones behind them
 __host__ __device__ inline uint32_t variant_among_allowed(uint32_t preferred, uint32_t allowedMask)
 {
-    for (uint32_t v = preferred; v > 1; --v)
-        if ((allowedMask >> v) & 1u) return v == 3 && preferred == 2 ? 1u : v;       // (never the rings for loose locality)
-    return 1u;
+    for (uint32_t v = preferred; v >= 1; --v)
+        if ((allowedMask >> v) & 1u) {
+            if (v == 3 && preferred == 2) continue;      // loose locality: global atomics before the rings, if they are there
+            return v;
+        }
+    for (uint32_t v = preferred + 1; v <= 3; ++v)
+        if ((allowedMask >> v) & 1u) return v;
+    return ((allowedMask >> 3) & 1u) ? 3u : 1u;
 }
 // variant worth taking for a sample (outside variant 2's window, tuples seen, outside variant 3's ring)
 // dup = sampled tuples that share their home slot with another tuple of their tile: rings with few duplicate keys take the
@@ -206,7 +251,11 @@ __host__ __device__ inline uint32_t variant_for_sample(uint64_t outOwn, uint64_t
     // farRows: sampled rows of 64 tuples that reach above the row two further on (disorder beyond 64 positions: more than
     // the compact build's seam zones cover -- it would start, give up and hand over to the classic rings)
     if (canWave && outWave * 128 <= seen) return (canCompact && dup * 8 <= seen && farRows == 0) ? 4 : 3;
-    if (canOwn && outOwn * 12 <= seen) return 2;
+    // the workgroup window while it can take at least a quarter of the tuples itself: what it defers is finished by global
+    // atomics at about their own pace (2^27, local_shuffle, build + probe: W = 2^12 defers 36 % -> 2.8 ms against 5.8 ms
+    // for the global-atomic build; 2^13: 71 % -> 4.7 / 5.8; 2^14: 88 % -> 5.6 / 5.9; 2^16: 97 % -> 6.6 / 5.9 -- since the
+    // deferred queue is sliced per workgroup; with one global queue counter the window lost from 8 % on)
+    if (canOwn && outOwn * 4 <= seen * 3) return 2;
     return 1;
 }
 hipError_t own_set_attributes();          // per device, at hj_create
@@ -214,15 +263,14 @@ hipError_t own_set_attributes();          // per device, at hj_create
 // Writes every table slot exactly once: no separate launch_fill_empty needed.
 hipError_t launch_build_own(const void* R, bool key32, uint64_t n, uint32_t hshift, uint64_t* table,
                             uint64_t tableSize, uint32_t probeLen, uint64_t idxBase, ShardCheck sc, int nCU, void* ownerBuf,
-                            void* queueBuf, unsigned long long* queueCount, Counters* ctr, Gate gate, int parts,
+                            void* queueBuf, uint32_t* deferCounts, Counters* ctr, Gate gate, int parts,
                             hipEvent_t evPhaseA, hipStream_t s, const KernelEvents* kev = nullptr,
                             uint64_t* htmConflicts = nullptr, uint32_t* htmCounts = nullptr);   // parts: 1 = phase A (up to evPhaseA), 2 = the rest, 3 = both
 // htmConflicts != nullptr: the bucketised table of --algo htm through the workgroup window (tuples only, probeLen 3): the
 // tuples that find their bucket full are listed per chunk, plus one last slice for the deferred phase's (own_conflict_layout)
 
-// phase B alone: finishes the queued tuples with global atomics (shared with variant 3)
-void launch_build_deferred(const void* queueBuf, const unsigned long long* queueCount, uint64_t* table, uint64_t tableSize,
-                           uint32_t hshift, uint32_t probeLen, Counters* ctr, Gate gate, hipStream_t s);
+// deferCounts: kOwnMaxChunks words (the deferred queue is sliced by phase-A workgroup; entries per slice)
+constexpr uint32_t kOwnMaxChunks = 8192;
 
 // ---- wavefront-private build (defined in hj_build_wave.hip) ------------------
 // geometry the locality sampler (k_sample_locality) needs to predict what k_build_wave would defer
@@ -246,7 +294,9 @@ hipError_t launch_build_wave(const void* R, bool key32, uint64_t n, uint32_t hsh
                              uint32_t probeLen, uint64_t idxBase, ShardCheck sc, int nCU, void* boundsBuf, void* queueBuf,
                              Counters* ctr, Gate gate, int parts, hipEvent_t evPhaseA, hipStream_t s,
                              uint64_t* htmConflicts = nullptr, int mode = kWaveClassic, uint32_t fallbackVariant = 3,
-                             const KernelEvents* kev = nullptr);
+                             const KernelEvents* kev = nullptr, bool htmRoute = false);
+// htmRoute: the deferred phase files its conflicts under the chunk that owns their bucket (the LDS chain phase needs that)
+const uint32_t* wave_bounds_ptr(int nCU, const void* boundsBuf);     // chunk c owns granules [bounds[c], bounds[c + 1])
 bool wave_compact_supported(uint64_t tableSize, uint32_t probeLen);
 void launch_set_variant(Counters* ctr, uint32_t v, hipStream_t s);
 // htmConflicts != nullptr: the bucketised table of --algo htm (home_slot_htm, probeLen must be 3, tuples only); every
@@ -270,6 +320,14 @@ hipError_t launch_htm_count(const uint64_t* conflicts, const uint32_t* ccounts, 
 hipError_t launch_htm_chains(const uint64_t* conflicts, const uint32_t* ccounts, uint32_t nSlices, uint32_t sliceLen,
                              uint64_t* table, uint32_t numBuckets, const unsigned int* ovfCount, const uint32_t* ovfBase,
                              uint64_t* overflow, uint64_t overflowCapBuckets, Counters* ctr, hipStream_t s);
+// the chain phase in LDS, after the ring build with routed conflicts (hj_htm.hip): count -> partGroups[nSlices * parts] (overflow
+// buckets per part; scan it, one word more for the total) and info (htm_chain_info_words words); fill builds the chains
+uint32_t htm_chain_parts(uint32_t sliceLen);
+size_t htm_chain_info_words(uint32_t nSlices, uint32_t sliceLen);
+hipError_t launch_htm_chain_count(const uint64_t* conflicts, const uint32_t* ccounts, const uint32_t* bounds, uint32_t nSlices,
+                                  uint32_t sliceLen, uint32_t numBuckets, uint32_t* partGroups, uint32_t* info, Counters* ctr, hipStream_t s);
+hipError_t launch_htm_chain_fill(const uint64_t* conflicts, uint32_t nSlices, uint32_t sliceLen, uint32_t numBuckets, const uint32_t* partBase,
+                                 const uint32_t* info, uint64_t* table, uint64_t* overflow, Counters* ctr, hipStream_t s);
 void launch_htm_probe(const uint64_t* S, uint64_t n, const uint64_t* table, uint32_t numBuckets, const uint64_t* overflow,
                       Counters* ctr, hipStream_t s);
 void launch_htm_sums(const uint64_t* table, uint32_t numBuckets, const uint64_t* overflow, Counters* ctr, hipStream_t s);

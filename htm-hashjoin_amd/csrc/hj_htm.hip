@@ -153,6 +153,189 @@ k_htm_link(uint64_t* __restrict__ table, uint32_t numBuckets, const unsigned int
     if ((threadIdx.x & 63) == 0 && groupsSeen) atomicAdd(&ctr->htmOverflowBuckets, groupsSeen);
 }
 
+// ---- chains along the rings: the whole phase in LDS (round 3) ----------------------------------------------------------------
+// The generic kernels above are bound by memory-side atomics (k_htm_count one per conflict, k_htm_fill_overflow a priority
+// walk per conflict, 30-45 G atomics/s: 2.6 ms for the 30 M conflicts of `uniform` at 2^27) and by three passes over
+// per-bucket arrays of the whole table (groups, scan, link: 1.2 ms). After the ring build (k_build_wave<HTM>) none of that is
+// needed: chunk c's wavefront only ever inserts into the slot range it owns, [bounds[c], bounds[c + 1]) granules = 32
+// buckets each, so the conflicts it lists are conflicts of ITS buckets, and the deferred phase files the few it finds
+// under the chunk that owns their bucket (k_wave_deferred<HTM>, route). A slice of the conflict list then holds ALL
+// conflicts of a contiguous bucket range, and a workgroup can do for that range in LDS what the generic kernels do in HBM:
+//   count      (k_htm_chain_count, one workgroup per slice) the bucket range the slice's conflicts really span, one LDS
+//              counter per bucket of it (direct index), the range cut into `parts` equal sub-ranges; per part: overflow
+//              buckets needed (sum of ceil(count / 3)) -> partGroups, and the stretch of the list its conflicts lie in
+//              (near-sorted keys: about a parts-th of the slice) -> info
+//   (host)     exclusive scan of partGroups: where each part's overflow buckets start (a part's buckets are neighbours,
+//              ordered by bucket -- as with the generic scan over buckets, only the numbering differs)
+//   fill       (k_htm_chain_fill, one workgroup per part) counters of the sub-range again, exclusive scan of the groups,
+//              the conflicts inserted by index priority into an LDS image of the part's overflow buckets (LDS atomicMin:
+//              the same walk as k_htm_fill_overflow), and the image written out whole: 32 bytes per overflow bucket, tuple
+//              slots and link word at once, plus the link word of each primary bucket with conflicts. No global atomics,
+//              no per-bucket arrays, no memset of the overflow area.
+// Anything that does not fit (a slice spanning more than kChainCountCap buckets: sparse keys; a part of more than kChainCap
+// buckets or image slots: many duplicates; a conflict outside its slice's range) raises Counters::htmChainBail, and the
+// host redoes the build without routing and chains with the generic kernels.
+constexpr int kChainThreads = 512;
+constexpr uint32_t kChainCountCap = 12288;           // buckets a slice's conflicts may span (k_htm_chain_count's LDS counters)
+constexpr uint32_t kChainCap = 3072;                 // buckets per part = the fill's LDS counters; tuple slots of its overflow image (36 KiB: 4 workgroups per CU)
+constexpr uint32_t kChainMaxParts = 16;
+
+__device__ __forceinline__ uint32_t chain_block_exclusive_scan(uint32_t v, uint32_t* wsum /*[kChainThreads / 64]*/, uint32_t& total)
+{
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t n = (uint32_t)__shfl_up((int)inc, off, 64);
+        if ((int)lane >= off) inc += n;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < kChainThreads / 64; ++k) { const uint32_t x = wsum[k]; if (k < (int)w) wbase += x; tot += x; }
+    total = tot;
+    __syncthreads();
+    return wbase + inc - v;
+}
+
+// info: per slice 2 words (first bucket of the span, buckets per part), then per part 2 words (its stretch of the list)
+__global__ void __launch_bounds__(kChainThreads)
+k_htm_chain_count(const uint64_t* __restrict__ conflicts, const uint32_t* __restrict__ ccounts, const uint32_t* __restrict__ bounds,
+                  uint32_t nSlices, uint32_t sliceLen, uint32_t parts, uint32_t numBuckets, uint32_t* __restrict__ partGroups,
+                  uint32_t* __restrict__ info, Counters* __restrict__ ctr)
+{
+    __shared__ uint32_t cnt[kChainCountCap];
+    __shared__ uint32_t sMin, sMaxInv, sStray, sBail;
+    __shared__ uint32_t pGroups[kChainMaxParts], pFirst[kChainMaxParts], pLastInv[kChainMaxParts];
+    const uint32_t c = blockIdx.x;
+    if (threadIdx.x == 0) {
+        sBail = *reinterpret_cast<volatile unsigned long long*>(&ctr->htmChainBail) != 0;
+        sMin = 0xFFFFFFFFu; sMaxInv = 0xFFFFFFFFu; sStray = 0;
+    }
+    if (threadIdx.x < kChainMaxParts) { pGroups[threadIdx.x] = 0; pFirst[threadIdx.x] = 0xFFFFFFFFu; pLastInv[threadIdx.x] = 0xFFFFFFFFu; }
+    __syncthreads();
+    if (sBail) return;
+    const uint32_t m = ccounts[c];
+    uint32_t* const sInfo = info + 2 * (size_t)c;
+    uint32_t* const pInfo = info + 2 * (size_t)nSlices + 2 * (size_t)c * parts;
+    auto bail = [&]() { if (threadIdx.x == 0) atomicExch(&ctr->htmChainBail, 1ull); };
+    if (m > sliceLen) { bail(); return; }
+    if (m == 0) {
+        if (threadIdx.x == 0) { sInfo[0] = 0; sInfo[1] = 0; }
+        if (threadIdx.x < parts) { partGroups[c * parts + threadIdx.x] = 0; pInfo[2 * threadIdx.x] = 0; pInfo[2 * threadIdx.x + 1] = 0; }
+        return;
+    }
+    const uint64_t* __restrict__ q = conflicts + (uint64_t)c * sliceLen;
+    const uint32_t bucketMask = numBuckets - 1;
+    // what the chunk owns (first and last chunk: also what lies outside every chunk's range), and what its conflicts span
+    const uint32_t B0 = c ? bounds[c] * 32u : 0u, B1 = (c + 1 == nSlices) ? numBuckets : bounds[c + 1] * 32u;
+    uint32_t lo = 0xFFFFFFFFu, hiInv = 0xFFFFFFFFu;
+    bool stray = false;
+    for (uint32_t i = threadIdx.x; i < m; i += kChainThreads) {
+        const uint32_t b = ((uint32_t)q[i] / 3u) & bucketMask;
+        stray |= (b < B0) | (b >= B1);
+        lo = b < lo ? b : lo; hiInv = ~b < hiInv ? ~b : hiInv;
+    }
+    atomicMin(&sMin, lo); atomicMin(&sMaxInv, hiInv);
+    if (stray) sStray = 1;
+    __syncthreads();
+    const uint32_t E0 = sMin, span = ~sMaxInv - E0 + 1u;
+    const uint32_t sub = (span + parts - 1) / parts;                           // buckets per part
+    if (sStray || span > kChainCountCap || sub > kChainCap) { bail(); return; }   // (a conflict filed under the wrong chunk: not this path)
+    for (uint32_t i = threadIdx.x; i < span; i += kChainThreads) cnt[i] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < m; i += kChainThreads) {
+        const uint32_t b = (((uint32_t)q[i] / 3u) & bucketMask) - E0;
+        atomicAdd(&cnt[b], 1u);
+        // the part's stretch of the list: near-sorted keys put a whole wavefront into one part -- one lane speaks for it
+        // (64 lanes on one LDS address are served one after the other)
+        const uint32_t p = b / sub;
+        const uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
+        const unsigned long long act = __ballot(1), same = __ballot(p == p0);
+        if (same == act) {
+            const uint32_t first = (uint32_t)__ffsll((long long)act) - 1u, last = 63u - (uint32_t)__clzll((long long)act);
+            const uint32_t lane = threadIdx.x & 63u;
+            if (lane == first) atomicMin(&pFirst[p0], i);
+            if (lane == last) atomicMin(&pLastInv[p0], ~i);
+        } else {
+            atomicMin(&pFirst[p], i); atomicMin(&pLastInv[p], ~i);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < span; i += kChainThreads) {
+        const uint32_t g = (cnt[i] + 2u) / 3u;
+        if (g) atomicAdd(&pGroups[i / sub], g);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { sInfo[0] = E0; sInfo[1] = sub; }
+    if (threadIdx.x < parts) {
+        const uint32_t g = pGroups[threadIdx.x];
+        if (3u * g > kChainCap) atomicExch(&ctr->htmChainBail, 1ull);
+        partGroups[c * parts + threadIdx.x] = g;
+        pInfo[2 * threadIdx.x] = g ? pFirst[threadIdx.x] : 0u;
+        pInfo[2 * threadIdx.x + 1] = g ? ~pLastInv[threadIdx.x] + 1u : 0u;
+    }
+}
+
+__global__ void __launch_bounds__(kChainThreads)
+k_htm_chain_fill(const uint64_t* __restrict__ conflicts, uint32_t nSlices, uint32_t sliceLen, uint32_t parts, uint32_t numBuckets,
+                 const uint32_t* __restrict__ partBase, const uint32_t* __restrict__ info, uint64_t* __restrict__ table,
+                 uint64_t* __restrict__ overflow, Counters* __restrict__ ctr)
+{
+    __shared__ uint32_t cnt[kChainCap];              // per bucket of the part: conflicts | first group of the bucket << 16
+    __shared__ unsigned long long image[kChainCap];  // the part's overflow buckets, three tuple slots each
+    __shared__ uint32_t wsum[kChainThreads / 64];
+    const uint32_t c = blockIdx.x / parts, p = blockIdx.x - c * parts;
+    const uint32_t base = partBase[blockIdx.x], total = partBase[blockIdx.x + 1] - base;   // (one word more than parts: the grand total)
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) ctr->htmOverflowBuckets = (unsigned long long)base + total;
+    if (total == 0) return;
+    const uint32_t E0 = info[2 * (size_t)c], sub = info[2 * (size_t)c + 1];
+    const uint32_t i0 = info[2 * (size_t)nSlices + 2 * (size_t)blockIdx.x], i1 = info[2 * (size_t)nSlices + 2 * (size_t)blockIdx.x + 1];
+    const uint64_t* __restrict__ q = conflicts + (uint64_t)c * sliceLen;
+    const uint32_t bucketMask = numBuckets - 1, lo = E0 + p * sub;
+    for (uint32_t i = threadIdx.x; i < sub; i += kChainThreads) cnt[i] = 0;
+    for (uint32_t i = threadIdx.x; i < 3u * total; i += kChainThreads) image[i] = kEmpty;
+    __syncthreads();
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += kChainThreads) {
+        const uint32_t b = (((uint32_t)q[i] / 3u) & bucketMask) - lo;
+        if (b < sub) atomicAdd(&cnt[b], 1u);
+    }
+    __syncthreads();
+    // first group of every bucket: exclusive scan of ceil(count / 3) over the part, thread t takes `per` consecutive buckets
+    const uint32_t per = (sub + kChainThreads - 1) / kChainThreads;
+    const uint32_t f0 = threadIdx.x * per < sub ? threadIdx.x * per : sub, f1 = f0 + per < sub ? f0 + per : sub;
+    uint32_t mine = 0;
+    for (uint32_t i = f0; i < f1; ++i) mine += (cnt[i] + 2u) / 3u;
+    uint32_t tot;
+    uint32_t run = chain_block_exclusive_scan(mine, wsum, tot);
+    for (uint32_t i = f0; i < f1; ++i) { const uint32_t k = cnt[i]; cnt[i] = k | (run << 16); run += (k + 2u) / 3u; }
+    __syncthreads();
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += kChainThreads) {
+        unsigned long long x = q[i];
+        const uint32_t b = (((uint32_t)x / 3u) & bucketMask) - lo;
+        if (b >= sub) continue;
+        const uint32_t w = cnt[b], k = w & 0xFFFFu, at = 3u * (w >> 16);
+        for (uint32_t d = 0; d < k; ++d) {                                    // index priority, as k_htm_fill_overflow
+            const unsigned long long old = atomicMin(&image[at + d], x);
+            if (old == kEmpty) break;
+            if (old > x) x = old;
+        }
+    }
+    __syncthreads();
+    for (uint32_t G = threadIdx.x; G < total; G += kChainThreads) {
+        const unsigned long long t0 = image[3u * G], t1 = image[3u * G + 1], t2 = image[3u * G + 2];
+        const uint32_t b = ((uint32_t)t0 / 3u) & bucketMask;                  // a group's first slot is never empty
+        const uint32_t w = cnt[b - lo], k = w & 0xFFFFu, gb = w >> 16, g = (k + 2u) / 3u, j = G - gb;
+        const uint64_t id = 1ull + base + G;                                  // overflow buckets are numbered from 1
+        const unsigned long long link = ((unsigned long long)(j ? id - 1 : 0ull) << 32) | (j + 1 < g ? 3u : k - 3u * (g - 1u));
+        ulonglong2* dst = reinterpret_cast<ulonglong2*>(overflow + (id << 2));
+        dst[0] = make_ulonglong2(t0, t1);
+        dst[1] = make_ulonglong2(t2, link);
+        if (j == 0) table[((uint64_t)b << 2) + 3] = ((unsigned long long)(id + g - 1u) << 32) | 3u;   // head = the newest overflow bucket
+    }
+}
+
 // (count, next) of a bucket whose four words are a, b, c (tuple slots) and m (slot 3)
 __device__ __forceinline__ uint32_t htm_next(uint64_t m) { return m == kEmpty ? 0u : (uint32_t)(m >> 32); }
 
@@ -246,6 +429,31 @@ hipError_t launch_htm_chains(const uint64_t* conflicts, const uint32_t* ccounts,
     hipLaunchKernelGGL(k_htm_fill_overflow, dim3(nSlices < 4096 ? nSlices : 4096), dim3(kBlock), 0, s, conflicts, ccounts, nSlices,
                        sliceLen, numBuckets - 1, ovfCount, ovfBase, overflow);
     hipLaunchKernelGGL(k_htm_link, dim3(2048), dim3(kBlock), 0, s, table, numBuckets, ovfCount, ovfBase, overflow, ctr);
+    return hipGetLastError();
+}
+
+uint32_t htm_chain_parts(uint32_t sliceLen)
+{
+    // ~4096 tuples' worth of keys per part: 1.4 k buckets on dense keys, a 1.5 k-slot image on `uniform` (half the LDS arrays)
+    const uint32_t p = (sliceLen + 4223u) / 4224u;
+    return p < 1 ? 1 : p > kChainMaxParts ? kChainMaxParts : p;
+}
+size_t htm_chain_info_words(uint32_t nSlices, uint32_t sliceLen) { return 2 * (size_t)nSlices * (1 + htm_chain_parts(sliceLen)); }
+
+hipError_t launch_htm_chain_count(const uint64_t* conflicts, const uint32_t* ccounts, const uint32_t* bounds, uint32_t nSlices,
+                                  uint32_t sliceLen, uint32_t numBuckets, uint32_t* partGroups, uint32_t* info, Counters* ctr, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_htm_chain_count, dim3(nSlices), dim3(kChainThreads), 0, s, conflicts, ccounts, bounds, nSlices, sliceLen,
+                       htm_chain_parts(sliceLen), numBuckets, partGroups, info, ctr);
+    return hipGetLastError();
+}
+
+hipError_t launch_htm_chain_fill(const uint64_t* conflicts, uint32_t nSlices, uint32_t sliceLen, uint32_t numBuckets, const uint32_t* partBase,
+                                 const uint32_t* info, uint64_t* table, uint64_t* overflow, Counters* ctr, hipStream_t s)
+{
+    const uint32_t parts = htm_chain_parts(sliceLen);
+    hipLaunchKernelGGL(k_htm_chain_fill, dim3(nSlices * parts), dim3(kChainThreads), 0, s, conflicts, nSlices, sliceLen, parts, numBuckets,
+                       partBase, info, table, overflow, ctr);
     return hipGetLastError();
 }
 

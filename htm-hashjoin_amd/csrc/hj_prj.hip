@@ -516,6 +516,9 @@ constexpr uint32_t kMaxInFrags = 1024;     // pass-1 fragments one pass-2 chunk 
 #define HJ_FRAG1_E 32
 #define HJ_FRAG1_WPE 4
 #endif
+#ifndef HJ_FRAG1_LANECOL
+#define HJ_FRAG1_LANECOL 1                    // pass 1 ranks into per-(bin, lane column) counters (k_radix_scatter_frag)
+#endif
 #ifndef HJ_FRAG2_NT
 #define HJ_FRAG2_NT 512
 #define HJ_FRAG2_E 16
@@ -534,16 +537,26 @@ struct FragPass {
     const uint32_t* inCnt;
 };
 
-template <bool IN32, int NT, int E = 16, int WPE = 4>         // E = elements per thread and tile
+// LANECOL (pass 1, tiles of 32768 keys): the ranking counters are kept per (bin, lane & 15) -- 16 columns per bin, so
+// the bank of a lane's counter is ((bin & 1) << 4 | lane & 15): whatever bins the 32 lanes of a group hold, at most two of
+// them meet on a bank, which a 4-cycle LDS atomic hides (MI355X_MICROARCH.md, LDS). Ranking 64 shuffled keys into one
+// counter per bin put 3-5 lanes on the busiest bank and serialised equal bins (r03_prj_pmc_sq.txt: 244 M conflict cycles
+// of 416 M LDS-active on the shuffled R against 104 M of 276 M on the sorted S). One word per counter: the count of the
+// current tile in the low half (<= 2048: 64 threads x 32 keys share a column), the counter's first staged position --
+// the exclusive scan over (bin, column), written by the scan that also resets the count -- in the high half (< 65536).
+// The scan is done by all threads (4 counters each) instead of one wavefront over 256 bins.
+template <bool IN32, int NT, int E = 16, int WPE = 4, bool LANECOL = false>         // E = elements per thread and tile
 __global__ void __launch_bounds__(NT, WPE)
 k_radix_scatter_frag(const void* __restrict__ in, uint32_t* __restrict__ out, FragPass p, Counters* __restrict__ ctr)
 {
     constexpr uint32_t TILE = (uint32_t)NT * E;
     static_assert(TILE <= 65536 && E % 2 == 0, "ranks are kept in 16 bits, two to a register");
+    static_assert(!LANECOL || (NT == 4 * kMaxFan && TILE < 65536), "LANECOL: four counters per thread, positions in 16 bits");
     constexpr uint32_t kPadShift = 5;                         // see k_radix_scatter
     constexpr uint32_t kDump = TILE + (TILE >> kPadShift);
     __shared__ uint32_t stage[kDump + 1];
-    __shared__ unsigned int tileCnt[kMaxFan], tileOff[kMaxFan], delta[kMaxFan], cursor[kMaxFan];
+    __shared__ unsigned int tileCnt[LANECOL ? 1 : kMaxFan], tileOff[LANECOL ? 1 : kMaxFan], delta[kMaxFan], cursor[kMaxFan];
+    __shared__ uint4 colCnt[LANECOL ? kMaxFan * 4 : 1];       // LANECOL: [bin][16 columns], as uint4 for the scan
     __shared__ unsigned int sValid, sAbort;
     __shared__ uint32_t prefix[IN32 ? kMaxInFrags + 1 : 1];   // pass 2: keys of this chunk before input fragment i
     __shared__ uint32_t wsum[NT / 64];
@@ -593,9 +606,10 @@ k_radix_scatter_frag(const void* __restrict__ in, uint32_t* __restrict__ out, Fr
         return;
     }
     if (threadIdx.x < kMaxFan) {
-        tileCnt[threadIdx.x] = 0;
+        if constexpr (!LANECOL) tileCnt[threadIdx.x] = 0;
         cursor[threadIdx.x] = threadIdx.x < p.fan ? frag_start(threadIdx.x) : 0;
     }
+    if constexpr (LANECOL) colCnt[threadIdx.x] = uint4{0u, 0u, 0u, 0u};
     if (threadIdx.x == 0) sAbort = 0;
     __syncthreads();
 
@@ -607,6 +621,7 @@ k_radix_scatter_frag(const void* __restrict__ in, uint32_t* __restrict__ out, Fr
         // one add away, and hoisted out of the loop it only fills registers until they spill
         uint32_t tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
+        unsigned int* const colWord = reinterpret_cast<unsigned int*>(colCnt) + (tid & 15u);   // LANECOL: + 16 * bin
         uint32_t tv[E], okMask = 0;
         if constexpr (!IN32) {
             // one register per element instead of two (the payload word is never looked at, as in mc: the partition
@@ -656,10 +671,34 @@ k_radix_scatter_frag(const void* __restrict__ in, uint32_t* __restrict__ out, Fr
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             const uint32_t bin = (tv[j] >> p.shift) & fmask;
-            const uint32_t r = atomicAdd(&tileCnt[bin], (okMask >> j) & 1u);
+            uint32_t r;
+            if constexpr (LANECOL) r = atomicAdd(&colWord[bin << 4], (okMask >> j) & 1u) & 0xFFFFu;
+            else r = atomicAdd(&tileCnt[bin], (okMask >> j) & 1u);
             if (j & 1) rk[j / 2] |= r << 16; else rk[j / 2] = r;
         }
         __syncthreads();
+        if constexpr (LANECOL) {
+            // ---- all threads: scan of the 4096 counters (thread t: bin t / 4, columns 4 (t % 4) ..), cursors, capacity check ----
+            const uint4 w = colCnt[tid];
+            const uint32_t c0 = w.x & 0xFFFFu, c1 = w.y & 0xFFFFu, c2 = w.z & 0xFFFFu, c3 = w.w & 0xFFFFu;
+            const uint32_t mine = c0 + c1 + c2 + c3;
+            uint32_t tot;
+            const uint32_t ex = block_exclusive_scan<NT>(mine, wsum, tot);
+            colCnt[tid] = uint4{ex << 16, (ex + c0) << 16, (ex + c0 + c1) << 16, (ex + c0 + c1 + c2) << 16};
+            const uint32_t endOfBin = (uint32_t)__shfl_down((int)(ex + mine), 3, 64);     // the four threads of a bin share a wavefront
+            if ((tid & 3u) == 0) {
+                const uint32_t b = tid >> 2, cnt = endOfBin - ex;
+                const uint32_t cu = cursor[b];
+                delta[b] = cu - ex;
+                cursor[b] = cu + cnt;
+                if (b < p.fan && cu + cnt - frag_start(b) > p.outCap) { sAbort = 1; atomicExch(&ctr->prjFallback, 1ull); }
+            }
+            if (tid == 0) {
+                sValid = tot;
+                // someone else's overflow: looked at every 16th tile
+                if ((tileNo & 15u) == 15u && *reinterpret_cast<volatile unsigned long long*>(&ctr->prjFallback) != 0) sAbort = 1;
+            }
+        } else
         // ---- one wavefront: scan of the counters, cursors, capacity check ----
         if (tid < 64) {
             const uint32_t b4 = 4 * tid;
@@ -694,7 +733,8 @@ k_radix_scatter_frag(const void* __restrict__ in, uint32_t* __restrict__ out, Fr
         // ---- stage ----
 #pragma unroll
         for (int k = 0; k < E; ++k) {
-            const uint32_t at = tileOff[(tv[k] >> p.shift) & fmask] + ((rk[k / 2] >> (16 * (k & 1))) & 0xFFFFu);
+            const uint32_t binK = (tv[k] >> p.shift) & fmask;
+            const uint32_t at = (LANECOL ? colWord[binK << 4] >> 16 : tileOff[binK]) + ((rk[k / 2] >> (16 * (k & 1))) & 0xFFFFu);
             stage[((okMask >> k) & 1u) ? at + (at >> kPadShift) : kDump] = tv[k];
         }
         __syncthreads();
@@ -1168,7 +1208,7 @@ hipError_t partition_relation_frag(const PrjPlan& pl, const PrjFrag& g, const Wo
     const uint32_t F1 = 1u << pl.bits1, F2 = 1u << pl.bits2;
     const FragPass p1{g.C1, 0u, F1, g.cap1, w.cnt1, (uint32_t)n, g.chunkLen1, 0u, 0u, nullptr};
     if (evS0) (void)hipEventRecord(evS0, s);
-    hipLaunchKernelGGL((k_radix_scatter_frag<false, HJ_FRAG1_NT, HJ_FRAG1_E, HJ_FRAG1_WPE>), dim3(g.C1), dim3(HJ_FRAG1_NT), 0, s, static_cast<const void*>(in), tmp, p1, ctr);
+    hipLaunchKernelGGL((k_radix_scatter_frag<false, HJ_FRAG1_NT, HJ_FRAG1_E, HJ_FRAG1_WPE, HJ_FRAG1_LANECOL != 0>), dim3(g.C1), dim3(HJ_FRAG1_NT), 0, s, static_cast<const void*>(in), tmp, p1, ctr);
     if (evS1) (void)hipEventRecord(evS1, s);
     const FragPass p2{g.C2, pl.bits1, F2, g.cap2, cnt2, 0u, 0u, g.C1 / g.C2, g.cap1, w.cnt1};
     hipLaunchKernelGGL((k_radix_scatter_frag<true, HJ_FRAG2_NT, HJ_FRAG2_E, HJ_FRAG2_WPE>), dim3(F1 * g.C2), dim3(HJ_FRAG2_NT), 0, s, static_cast<const void*>(tmp), out, p2, ctr);

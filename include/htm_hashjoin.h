@@ -143,7 +143,10 @@ typedef struct {
                                      tried; else why it handed over to the classic build -- bit 0: a tuple outside
                                      ring and range (no locality there), bit 1: more than 64 walks across one seam,
                                      bit 2: key 0xFFFFFFFF, bit 3: a tuple far below its chunk's range, bit 4: a
-                                     seam's two sides disagree (the shadow granule missed a tuple)                */
+                                     seam's two sides disagree (the shadow granule missed a tuple).
+                                     HJ_ALGO_HTM: bit 8 = the chain phase could not run in LDS behind the ring build (key
+                                     range of a chunk or its conflicts too large for the LDS image) and the generic
+                                     chain kernels redid it                                                            */
 } hj_result;
 
 typedef struct hj_ctx hj_ctx;

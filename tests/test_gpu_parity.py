@@ -128,6 +128,36 @@ def test_auto_variant_follows_locality(ctx):
         check_oa(got, oracle.build_probe_seq(R, Sx, 4))
 
 
+def test_a_context_follows_its_relation_from_step_to_step():
+    """hj_build_dev with buildVariant 0 on a reserved context enqueues only the kernels of the variant the PREVIOUS build's
+    sample preferred (no global-atomic safety net behind the LDS builds: they are correct on any input). A relation that
+    changes its locality class between two builds therefore takes one step on whatever was enqueued -- the rings with
+    everything deferred, or global atomics on sorted keys -- and the next step follows the sample. Every step's table is
+    the sequential one, slot for slot; buildVariant shows the road taken."""
+    n = 1 << 18
+    S = np.arange(1, n + 1, dtype=np.uint64)
+    rel = {k: oracle.generate_data(k[0], n, n, k[1]) for k in (("sorted", 16), ("shuffle", 16), ("local_shuffle", 1024), ("uniform", 16))}
+    want = {k: oracle.build_probe_seq(R, S, 4, want_table=True) for k, R in rel.items()}
+    steps = [(("sorted", 16), 4), (("sorted", 16), 4),                       # first build: everything enqueued
+             (("shuffle", 16), 3), (("shuffle", 16), 1),                     # locality lost: the classic rings defer it all, then global atomics
+             (("sorted", 16), 1), (("sorted", 16), 4),                       # and back: one step on global atomics
+             (("local_shuffle", 1024), 3), (("local_shuffle", 1024), 2),     # looser: the rings (behind the compact ones) once, then the window
+             (("uniform", 16), 2), (("uniform", 16), 3),                     # duplicate-heavy and tight: the window once, then the classic rings
+             (("sorted", 16), 3), (("sorted", 16), 4)]
+    with hj.HashJoinContext(0) as c:
+        dR = c.dev_alloc(n * 8); dS = c.dev_alloc(n * 8)
+        c.copy_h2d(dS, S)
+        c.reserve("atomic", n, n)
+        for key, variant in steps:
+            c.copy_h2d(dR, rel[key])
+            c.build(dR, n); c.probe(dS, n); c.checksums()
+            got = c.fetch()
+            assert got["buildVariant"] == variant, (key, got["buildVariant"], variant)
+            check_oa(got, want[key])
+            assert np.array_equal(c.export_table(2 * n), want[key]["table"]), key
+        c.dev_free(dR); c.dev_free(dS)
+
+
 def test_algo_auto_switches_between_table_and_radix_join(ctx):
     """HJ_ALGO_AUTO (the reference's adaptive idea, HTMHashBuild.hpp:98-154): inputs with locality take the
     no-partition path and give the open-addressing result bit for bit, inputs without it take the radix join and give
@@ -280,6 +310,10 @@ def test_htm_bucket_table_matches_sequential_oracle(ctx, dist, window, n, varian
         assert got["buildVariant"] == _variant_that_runs(variant, 4 * want["numBuckets"])
     elif n >= 1 << 16:                         # the pre-round with the table's own hash: rings / window / global atomics
         assert got["buildVariant"] == {("uniform", 16): 3, ("sorted", 16): 3, ("local_shuffle", 1024): 2}.get((dist, window), 1)
+    if got["buildVariant"] == 3 and dist in ("uniform", "sorted"):
+        assert got["compactFallback"] & 0x100 == 0     # near-sorted keys behind the rings: the chains were built in LDS (hj_htm.hip)
+    if got["buildVariant"] != 3:
+        assert got["compactFallback"] == 0
     buckets, overflows = ctx.export_buckets(want["numBuckets"])
     assert np.array_equal(buckets["tuples"], want["buckets"]["tuples"]) and np.array_equal(buckets["count"], want["buckets"]["count"])
     assert np.array_equal(buckets["nextIndex"] != 0, want["buckets"]["nextIndex"] != 0)
