@@ -888,9 +888,10 @@ k_build_wave(const void* __restrict__ Rv, uint64_t n, uint32_t sliceLen, uint32_
 
 // Phase B for the sliced deferred queue: chunk c's entries are queue[c * chunkLen .. + dcounts[c]). Same walk as
 // k_build_deferred (hj_build_own.hip): the probe walk of every deferred tuple finished with global atomics. The walks
-// are chains of dependent memory-side atomics (microseconds each), so the phase lasts as long as the longest sequence
-// one lane has to work through: a whole workgroup takes a slice at a time (a slice holds ~220 entries on `uniform` at
-// 2^30: every entry has its own lane at once; one wavefront per slice took four batches one after the other).
+// are chains of dependent memory-side atomics, and what bounds the phase is their THROUGHPUT, not its shape: 947 k entries
+// at 2^30 `uniform` take 101-107 us whether a workgroup takes a slice (round 2), a wavefront does (now), or the entries are
+// numbered through and dealt out to all lanes (round 3, binary search in a prefix of the counts: 104 us) -- 1.8 returning
+// 64-bit atomics per entry at the 17 G/s the global-atomic build reaches too.
 template <bool HTM>
 __global__ void __launch_bounds__(kBlock)
 k_wave_deferred(const DeferredEntry* __restrict__ queue, const uint32_t* __restrict__ dcounts, uint32_t nChunks,
@@ -901,11 +902,12 @@ k_wave_deferred(const DeferredEntry* __restrict__ queue, const uint32_t* __restr
     if (gate_closed(gate)) return;
     const uint32_t lane = threadIdx.x & 63;
     unsigned long long drops = 0, dropSum = 0;
-    for (uint32_t c = blockIdx.x; c < nChunks; c += gridDim.x) {
+    // a wavefront per slice (~220 entries per slice on `uniform` with one round of chunks, ~29 in each of 32768 slices at 2^30)
+    for (uint32_t c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); c < nChunks; c += gridDim.x * (kBlock / 64)) {
         const uint32_t cnt = dcounts[c];
         const DeferredEntry* q = queue + (uint64_t)c * chunkLen;
-        for (uint32_t i0 = 0; i0 < cnt; i0 += kBlock) {
-            const uint32_t i = i0 + threadIdx.x;
+        for (uint32_t i0 = 0; i0 < cnt; i0 += 64) {
+            const uint32_t i = i0 + lane;
             const bool has = i < cnt;
             uint64_t mine = has ? q[i].packed : 0ull;
             uint64_t pos = has ? q[i].pos : 0ull;
@@ -966,45 +968,45 @@ k_wave_deferred(const DeferredEntry* __restrict__ queue, const uint32_t* __restr
 
 // After k_build_wave: the valid slot range (hj_device.h, Counters) = the owned stretch [ownLo, ownHiEx) joined
 // with the blocks deferred tuples start from (+1: a probe walk spills at most probeLen - 1 slots). If it reaches
-// the table's end (walks wrap there) the whole table is made valid. Then the slots of the valid range (+512 slots of
-// defined contents past it, + the slack past the table) that no wavefront owned, [validLo, ownLo) and
-// [ownHiEx, validHiEx + 512), are set to empty. One launch: every workgroup folds the 64 counter shards for itself
-// (one wavefront, 2 x 64 loads that hit L2), workgroup 0 publishes the range for the deferred phase and the probe.
+// the table's end (walks wrap there) the whole table is made valid. One wavefront. (Round 3 tried this fold inside
+// k_wave_fill_edges, every workgroup for itself, to save the launch: 4 us at 2^22 -- and 55 us at 2^30, with 128 or
+// with 1024 workgroups, against 4.4 + 4.9 us for the two launches: taken back.)
+__global__ void k_wave_finalize_range(Counters* __restrict__ ctr, uint64_t tableSize, Gate gate)
+{
+    if (blockIdx.x != 0 || threadIdx.x >= 64 || gate_closed(gate)) return;
+    // the two maxima: what was written directly + the 64 shards (hj_device.h, Counters), one shard per lane
+    static_assert(Counters::kShards == 64, "one shard per lane of the single wavefront this kernel runs as");
+    unsigned long long usedLoInvAll = ctr->shard[threadIdx.x & 63].usedLoInv, usedHi1All = ctr->shard[threadIdx.x & 63].usedHi1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long a = __shfl_xor(usedLoInvAll, off, 64), b = __shfl_xor(usedHi1All, off, 64);
+        usedLoInvAll = a > usedLoInvAll ? a : usedLoInvAll; usedHi1All = b > usedHi1All ? b : usedHi1All;
+    }
+    usedLoInvAll = ctr->usedLoInv > usedLoInvAll ? ctr->usedLoInv : usedLoInvAll;
+    usedHi1All = ctr->usedHi1 > usedHi1All ? ctr->usedHi1 : usedHi1All;
+    if (threadIdx.x != 0) return;
+    unsigned long long lo = ctr->ownLo, hiEx = ctr->ownHiEx;
+    const unsigned long long hi1 = usedHi1All;
+    if (hi1) {
+        const unsigned long long dlo = (unsigned long long)(uint32_t)~(uint32_t)usedLoInvAll << 9, dhi = (hi1 + 1) << 9;
+        lo = dlo < lo ? dlo : lo; hiEx = dhi > hiEx ? dhi : hiEx;
+    }
+    if (hiEx + 512 >= tableSize) { lo = 0; hiEx = tableSize; }
+    ctr->validLo = lo; ctr->validHiEx = hiEx;
+}
+
+// Slots of the valid range (+512 slots of defined contents past it, + the slack past the table) that no wavefront
+// owned: [validLo, ownLo) and [ownHiEx, validHiEx + 512).
 __global__ void __launch_bounds__(kBlock)
-k_wave_fill_edges(uint64_t* __restrict__ table, Counters* __restrict__ ctr, uint64_t tableSize, Gate gate)
+k_wave_fill_edges(uint64_t* __restrict__ table, const Counters* __restrict__ ctr, uint64_t tableSize, Gate gate)
 {
     if (gate_closed(gate)) return;
-    __shared__ unsigned long long sLo, sHiEx;
-    if (threadIdx.x < 64) {
-        // the two maxima: what was written directly + the 64 shards (hj_device.h, Counters), one shard per lane
-        static_assert(Counters::kShards == 64, "one shard per lane of the wavefront that folds them");
-        unsigned long long usedLoInvAll = ctr->shard[threadIdx.x].usedLoInv, usedHi1All = ctr->shard[threadIdx.x].usedHi1;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long a = __shfl_xor(usedLoInvAll, off, 64), b = __shfl_xor(usedHi1All, off, 64);
-            usedLoInvAll = a > usedLoInvAll ? a : usedLoInvAll; usedHi1All = b > usedHi1All ? b : usedHi1All;
-        }
-        usedLoInvAll = ctr->usedLoInv > usedLoInvAll ? ctr->usedLoInv : usedLoInvAll;
-        usedHi1All = ctr->usedHi1 > usedHi1All ? ctr->usedHi1 : usedHi1All;
-        if (threadIdx.x == 0) {
-            unsigned long long lo = ctr->ownLo, hiEx = ctr->ownHiEx;
-            const unsigned long long hi1 = usedHi1All;
-            if (hi1) {
-                const unsigned long long dlo = (unsigned long long)(uint32_t)~(uint32_t)usedLoInvAll << 9, dhi = (hi1 + 1) << 9;
-                lo = dlo < lo ? dlo : lo; hiEx = dhi > hiEx ? dhi : hiEx;
-            }
-            if (hiEx + 512 >= tableSize) { lo = 0; hiEx = tableSize; }
-            sLo = lo; sHiEx = hiEx;
-            if (blockIdx.x == 0) { ctr->validLo = lo; ctr->validHiEx = hiEx; }      // nobody in this launch reads them
-        }
-    }
-    __syncthreads();
     const ulonglong2 e = make_ulonglong2(kEmpty, kEmpty);
     ulonglong2* t2 = reinterpret_cast<ulonglong2*>(table);
     const uint64_t stride = (uint64_t)gridDim.x * kBlock, t0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    uint64_t hi = sHiEx + 512;
+    uint64_t hi = ctr->validHiEx + 512;
     hi = hi < tableSize ? hi : tableSize;
-    const uint64_t a0 = sLo >> 1, a1 = ctr->ownLo >> 1;                   // all bounds are even (granules / blocks)
+    const uint64_t a0 = ctr->validLo >> 1, a1 = ctr->ownLo >> 1;          // all bounds are even (granules / blocks)
     for (uint64_t v = a0 + t0; v < a1; v += stride) t2[v] = e;
     const uint64_t b0 = ctr->ownHiEx >> 1, b1 = hi >> 1;
     for (uint64_t v = b0 + t0; v < b1; v += stride) t2[v] = e;
@@ -1195,8 +1197,9 @@ hipError_t launch_build_wave(const void* R, bool key32, uint64_t n, uint32_t hsh
         hipLaunchKernelGGL(k_wave_fill_edges_keys, dim3(512), dim3(kBlock), 0, s, reinterpret_cast<uint32_t*>(table), ctr, tableSize, gate);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_wave_fill_edges, dim3(1024), dim3(kBlock), 0, s, table, ctr, tableSize, gate);
-    const dim3 gDef(nChunks);                                  // one workgroup per slice
+    hipLaunchKernelGGL(k_wave_finalize_range, dim3(1), dim3(64), 0, s, ctr, tableSize, gate);
+    hipLaunchKernelGGL(k_wave_fill_edges, dim3(2048), dim3(kBlock), 0, s, table, ctr, tableSize, gate);
+    const dim3 gDef((nChunks + kBlock / 64 - 1) / (kBlock / 64));   // one wavefront per slice
     if (htm) hipLaunchKernelGGL(k_wave_deferred<true>, gDef, dim3(kBlock), 0, s, static_cast<const DeferredEntry*>(queueBuf), dcounts,
                                 nChunks, sliceLen, table, tableSize - 1, hshift, probeLen, ctr, gate, htmConflicts, ccounts,
                                 htmRoute ? bounds : nullptr);
