@@ -143,3 +143,31 @@ def test_config5_skew_stress_full_size():
     assert slices * per >= 4_000_000_000
     # the stream's head against the one-piece host generator at a smaller total (same seed, same alphabet: same prefix)
     assert np.array_equal(head[:4096], hj.generate_data("zipf", 4096, n, 16, zipf_theta=0.9))
+
+
+def test_htm_uniform_2p27_chains_in_lds_against_the_sequential_oracle():
+    """The bucketised table at the size its numbers are quoted at (2^27, `uniform`: 30 M conflicts in 17 M overflow
+    buckets): every counter of the sequential restatement of HTMHashBuild.hpp, through the ring build with the chain phase
+    in LDS (hj_htm.hip: `compactFallback` bit 8 clear = it did not hand over to the generic kernels) and, forced, through
+    the window build with the generic chain kernels."""
+    n = 1 << 27
+    R = hj.generate_data("uniform", n, n, 16)
+    S = hj.generate_data("sorted", n)
+    want = oracle.htm_build_probe_seq(R, S)
+    assert (want["conflictCount"], want["overflowBuckets"]) == (30065252, 17330401)       # DESIGN.md 4.6 quotes these
+    with hj.HashJoinContext(0) as c:
+        dR = c.dev_alloc(n * 8); c.copy_h2d(dR, R)
+        dS = c.dev_alloc(n * 8); c.copy_h2d(dS, S)
+        for variant in (0, 2):
+            c.reserve("htm", n, n, buildVariant=variant)
+            c.build(dR, n)
+            c.probe(dS, n)
+            c.checksums()
+            got = c.fetch()
+            assert got["buildVariant"] == (3 if variant == 0 else 2)
+            assert got["compactFallback"] == 0, (variant, got["compactFallback"])
+            assert (got["conflicts"], got["conflictSum"], got["totalMatches"], got["inputSum"], got["tableSumFull"],
+                    got["htmOverflowBuckets"], got["htmOverflowSum"], got["outputSum"]) == (
+                want["conflictCount"], want["conflictSum"], want["totalMatches"], want["inputSum"], want["bucketSum"],
+                want["overflowBuckets"], want["overflowSum"], want["outputSum"]), variant
+        c.dev_free(dR); c.dev_free(dS)
