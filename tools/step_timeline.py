@@ -12,13 +12,14 @@ def main():
         for r in csv.DictReader(open(f)):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    # a step starts at the sampler (variant 0) or, with a forced variant, at the first kernel after a k_table_sums
-    starts = [i for i, r in enumerate(rows) if "k_sample_locality" in r[2]]
-    if not starts:
-        ends = [i for i, r in enumerate(rows) if "k_table_sums" in r[2]]
-        starts = [e + 1 for e in ends[:-1]]
-    first = starts[-1]
-    last = max(i for i, r in enumerate(rows) if i >= first)
+    # a step = everything between two probes: the dispatches after the previous step's k_probe (and the copy of the counters
+    # that follows it) up to the last k_probe. (The locality sample of a context with a preference runs on a stream of its
+    # own beside the build: it shows up inside the step, overlapping its neighbours -- negative gaps.)
+    probes = [i for i, r in enumerate(rows) if "k_probe" in r[2]]
+    last = probes[-1]
+    first = probes[-2] + 1
+    while "copyBuffer" in rows[first][2]:
+        first += 1
     t0 = rows[first][0]
     prev_end = None
     busy = 0
