@@ -333,7 +333,20 @@ def launch_ranks(n_ranks, argv):
     reader.start()
     rc = 0
     alive = set(range(n_ranks))
+    # ranks that wait for each other forever (a collective one of them never joins) must not hold the caller forever
+    deadline = time.time() + float(os.environ.get("HJ_BENCH_RANKS_TIMEOUT_S", "2400"))
     while alive:
+        if time.time() > deadline:
+            print(f"bench.py --gpus {n_ranks}: ranks {sorted(alive)} still running after the time limit; stopping them", file=sys.stderr)
+            for o in alive:
+                procs[o].terminate()
+            for o in alive:
+                try:
+                    procs[o].wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    procs[o].kill()
+            rc = 5
+            break
         for r in list(alive):
             code = procs[r].poll()
             if code is None:
