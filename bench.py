@@ -253,7 +253,7 @@ def cpu_baseline(hj, log2n, dist, window, R=None):
     # the same loops on unique keys (what the reference's sweep runs, and what tools/sweep.py's CPU legs time): no retries,
     # no failed CAS -- several times the rate of the duplicate-heavy `uniform`; measured at 2^27 so that it costs a blink.
     # (Round 2 read this difference as a slowdown with size: the rate on `uniform` is 2.8-3.0 Gtuples/s at every size from
-    # 2^26 to 2^30, first-touched by the caller or by the worker threads alike -- tools/dbg/cpu_baseline_sizes.py.)
+    # 2^26 to 2^30, first-touched by the caller or by the worker threads alike -- tests/dev/cpu_baseline_sizes.py.)
     nu = 1 << min(27, log2n)
     Ru = hj.generate_data("local_shuffle", nu, nu, 16)
     Su = np.arange(1, nu + 1, dtype=np.uint64)

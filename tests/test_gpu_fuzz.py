@@ -1,0 +1,99 @@
+"""Randomised differential test of the open-addressing builds against the sequential oracle: inputs the DataGen
+distributions do not produce -- near-sorted multisets with bursts of equal keys, key domains from a quarter of the
+relation (most tuples are dropped) to the whole table (sparse keys, wrap-around at the table's end), disorder from none
+to far beyond what the rings hold, every probe length -- through the device's pick (0), the workgroup window (2), the
+classic rings (3) and the compact rings (4; where they cannot hold they must hand over, and the table must still be the sequential one).
+Counters and the whole table, slot for slot. HJ_FUZZ_CASES (default 36) sets the number of cases; the seed is fixed."""
+import os
+
+import numpy as np
+import pytest
+
+import htm_hashjoin_amd as hj
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def make_relation(rng, n):
+    """A near-sorted relation of n tuples (value = key, as DataGen's): sorted keys with bursts, then displaced by < W."""
+    table = 2 * n
+    kind = rng.integers(0, 5)
+    if kind == 0:          # dense unique keys
+        keys = np.arange(1, n + 1, dtype=np.uint64)
+    elif kind == 1:        # random multiset over a domain of n * f keys
+        f = rng.choice([0.25, 0.5, 1.0, 1.5, 1.99])
+        keys = np.sort(rng.integers(1, max(2, int(n * f)), size=n, dtype=np.uint64))
+    elif kind == 2:        # bursts: few distinct keys, geometric multiplicities
+        distinct = np.sort(rng.choice(np.arange(1, table, dtype=np.uint64), size=max(1, n // int(rng.integers(2, 9))), replace=False))
+        counts = rng.geometric(0.3, size=distinct.size)
+        keys = np.repeat(distinct, counts)[:n]
+        if keys.size < n:
+            keys = np.concatenate([keys, np.arange(1, n - keys.size + 1, dtype=np.uint64) + keys[-1]])
+        keys = np.sort(keys)
+    elif kind == 3:        # sparse keys over the whole table (walks wrap around its end) and a dense stretch at the very top
+        keys = np.sort(np.concatenate([rng.integers(1, table, size=n - n // 8, dtype=np.uint64),
+                                       np.arange(table - n // 8, table, dtype=np.uint64)]))
+    else:                  # two interleaved dense runs (every key twice, far apart in value order only by 1)
+        keys = np.sort(np.concatenate([np.arange(1, n // 2 + 1, dtype=np.uint64)] * 2))
+    keys = keys[:n].astype(np.uint64)
+    keys = np.sort((keys - np.uint64(1)) % np.uint64(table - 1) + np.uint64(1))        # into [1, table - 1], still sorted
+    w = int(rng.choice([1, 2, 4, 8, 16, 16, 16, 32, 48, 64, 100, 300, 2000]))
+    if w > 1:
+        order = np.argsort(np.arange(n) + rng.uniform(0, w, size=n), kind="stable")
+        keys = keys[order]
+    return np.ascontiguousarray(keys), w
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_ring_builds_on_random_near_sorted_relations(block):
+    cases = int(os.environ.get("HJ_FUZZ_CASES", "36"))
+    rng = np.random.default_rng(20260000 + block)
+    with hj.HashJoinContext(0) as ctx:
+        for case in range(block, cases, 4):
+            n = 1 << int(rng.integers(12, 21))
+            R, w = make_relation(rng, n)
+            plen = int(rng.choice([1, 2, 3, 4, 4, 4, 5, 8]))
+            S = np.ascontiguousarray(rng.permutation(R)[: n]) if rng.integers(0, 2) else np.arange(1, n + 1, dtype=np.uint64)
+            want = oracle.build_probe_seq(R, S, plen, want_table=True)
+            for variant in (0, 2, 3, 4):
+                got = ctx.run("atomic", R, S, probeLength=plen, buildVariant=variant)
+                tag = (block, case, n, w, plen, variant, got["buildVariant"], got["compactFallback"])
+                for k in ("conflicts", "totalMatches", "inputSum", "tableSumHalf", "tableSumFull", "conflictSum"):
+                    assert got[k] == want[k], (k, got[k], want[k], tag)
+                assert np.array_equal(ctx.export_table(2 * n), want["table"]), tag
+                if variant == 4 and got["buildVariant"] == 3:
+                    assert got["compactFallback"] != 0, tag              # a hand-over always says why
+                if variant == 3:
+                    assert got["buildVariant"] == 3 and got["compactFallback"] == 0, tag
+
+
+@pytest.mark.parametrize("block", range(2))
+def test_bucketised_table_on_random_near_sorted_relations(block):
+    """The same relations through --algo htm: rings with the chain phase in LDS (or, where that gives up, the generic
+    chain kernels: bit 8 of compactFallback), window, global atomics, and the device's pick -- every counter, the primary
+    buckets tuple for tuple, the overflow buckets as a multiset, and (small cases) every chain in walk order."""
+    cases = int(os.environ.get("HJ_FUZZ_CASES", "36")) // 2
+    rng = np.random.default_rng(20261000 + block)
+    with hj.HashJoinContext(0) as ctx:
+        for case in range(block, cases, 2):
+            n = 1 << int(rng.integers(10, 19))
+            R, w = make_relation(rng, n)
+            R = np.ascontiguousarray(R[: n - int(rng.integers(0, 3))])          # htm takes any size
+            S = np.ascontiguousarray(rng.permutation(R)) if rng.integers(0, 2) else np.arange(1, R.size + 1, dtype=np.uint64)
+            want = oracle.htm_build_probe_seq(R, S, want_buckets=True)
+            key = lambda o: np.sort(o[1:].view(np.uint64).reshape(-1, 4)[:, :3].sum(axis=1))          # noqa: E731
+            for variant in (0, 3, 2, 1):
+                got = ctx.run("htm", R, S, buildVariant=variant)
+                tag = (block, case, R.size, w, variant, got["buildVariant"], got["compactFallback"])
+                assert (got["conflicts"], got["conflictSum"], got["totalMatches"], got["inputSum"], got["tableSumFull"],
+                        got["htmOverflowBuckets"], got["htmOverflowSum"], got["outputSum"]) == (
+                    want["conflictCount"], want["conflictSum"], want["totalMatches"], want["inputSum"], want["bucketSum"],
+                    want["overflowBuckets"], want["overflowSum"], want["outputSum"]), tag
+                buckets, overflows = ctx.export_buckets(want["numBuckets"])
+                assert np.array_equal(buckets["tuples"], want["buckets"]["tuples"]) and np.array_equal(buckets["count"], want["buckets"]["count"]), tag
+                assert overflows.size == want["overflows"].size and np.array_equal(key(overflows), key(want["overflows"])), tag
+                if R.size <= 1 << 13:
+                    a, ao = oracle.htm_chains(buckets, overflows)
+                    b, bo = oracle.htm_chains(want["buckets"], want["overflows"])
+                    assert np.array_equal(ao, bo) and np.array_equal(a, b), tag
