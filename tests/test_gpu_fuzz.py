@@ -97,3 +97,41 @@ def test_bucketised_table_on_random_near_sorted_relations(block):
                     a, ao = oracle.htm_chains(buckets, overflows)
                     b, bo = oracle.htm_chains(want["buckets"], want["overflows"])
                     assert np.array_equal(ao, bo) and np.array_equal(a, b), tag
+
+
+@pytest.mark.parametrize("block", range(2))
+def test_radix_join_on_random_relations(block):
+    """--algo prj on relations of any size and shape: |R| != |S|, key domains from dense to 31 bits, skew in the low key bits
+    (pass 1 of the histogram-free path must give up and the exact passes redo the join), in the middle bits (pass 2 gives
+    up), many equal keys (partitions beyond one LDS table), through prjMode 0 (the size rule), 1 (exact passes) and 2
+    (histogram-free at any size) and several radix widths. Match count and the fork's checksum against the oracle."""
+    cases = int(os.environ.get("HJ_FUZZ_CASES", "36")) // 2
+    rng = np.random.default_rng(20262000 + block)
+    with hj.HashJoinContext(0) as ctx:
+        for case in range(block, cases, 2):
+            nr = int(rng.integers(1 << 10, 1 << 21))
+            ns = int(rng.integers(1 << 10, 1 << 21))
+            shape = int(rng.integers(0, 5))
+            if shape == 0:                                   # dense domain
+                hi = max(nr, ns)
+                R = rng.integers(1, hi + 1, size=nr, dtype=np.uint64); S = rng.integers(1, hi + 1, size=ns, dtype=np.uint64)
+            elif shape == 1:                                 # 31-bit keys (few matches)
+                R = rng.integers(1, 1 << 31, size=nr, dtype=np.uint64); S = np.concatenate([R[: min(nr, ns) // 2], rng.integers(1, 1 << 31, size=ns - min(nr, ns) // 2, dtype=np.uint64)])
+            elif shape == 2:                                 # low bits constant: one pass-1 bin takes everything
+                c = int(rng.integers(0, 256))
+                R = (rng.integers(1, 1 << 20, size=nr, dtype=np.uint64) << np.uint64(8)) | np.uint64(c); S = (rng.integers(1, 1 << 20, size=ns, dtype=np.uint64) << np.uint64(8)) | np.uint64(c)
+            elif shape == 3:                                 # middle bits constant: pass 2 cannot spread a partition
+                R = (rng.integers(1, 1 << 12, size=nr, dtype=np.uint64) << np.uint64(16)) | rng.integers(0, 256, size=nr, dtype=np.uint64)
+                S = (rng.integers(1, 1 << 12, size=ns, dtype=np.uint64) << np.uint64(16)) | rng.integers(0, 256, size=ns, dtype=np.uint64)
+            else:                                            # repeated keys: ~2 ... 64 tuples per key (more is quadratic work for any hash join, the oracle's included)
+                d = int(rng.integers(max(nr, ns) // 64 + 1, max(nr, ns)))
+                R = rng.integers(1, d + 1, size=nr, dtype=np.uint64); S = rng.integers(1, d + 1, size=ns, dtype=np.uint64)
+            R[R == 0] = 1; S[S == 0] = 1
+            bits = int(rng.choice([0, 8, 11, 12, 14, 16]))
+            for mode in (0, 1, 2):
+                got = ctx.run("prj", R, S, radixBits=bits, prjMode=mode)
+                want = oracle.prj_join(R, S, got["radixBits"])
+                tag = (block, case, nr, ns, shape, bits, mode, got["prjPath"])
+                assert (got["totalMatches"], got["prjChecksum"]) == (want["matches"], want["checksum"]), tag
+            if shape in (0, 1):
+                assert got["totalMatches"] == oracle.true_cardinality(R, S), (block, case)
