@@ -135,3 +135,39 @@ def test_radix_join_on_random_relations(block):
                 assert (got["totalMatches"], got["prjChecksum"]) == (want["matches"], want["checksum"]), tag
             if shape in (0, 1):
                 assert got["totalMatches"] == oracle.true_cardinality(R, S), (block, case)
+
+
+@pytest.mark.parametrize("block", range(2))
+def test_key_builds_of_a_radix_shard_on_random_keys(block):
+    """hj_build_keys_dev / hj_probe_keys_dev (what a radix shard runs on the 32-bit keys it received): any number of keys,
+    any home shift 0..6, tables from tight to roomy, unaligned key buffers, every probe length, all build variants --
+    counters and the whole table against the sequential oracle with the shard's table size and shift."""
+    cases = int(os.environ.get("HJ_FUZZ_CASES", "36")) // 2
+    rng = np.random.default_rng(20263000 + block)
+    for case in range(block, cases, 2):
+        n2 = 1 << int(rng.integers(11, 20))
+        keys64, w = make_relation(rng, n2)
+        shift = int(rng.integers(0, 7))
+        m = int(rng.integers(n2 // 2 + 1, n2 + 1))                          # the shard's share: any count
+        keys = np.ascontiguousarray(((keys64[:m] << np.uint64(shift)) | np.uint64(rng.integers(0, 1 << shift))).astype(np.uint32))
+        keys = keys[keys != 0]
+        m = keys.size
+        table_size = 2 * n2
+        plen = int(rng.choice([1, 2, 4, 4, 4, 8]))
+        S = np.ascontiguousarray(rng.permutation(keys)[: max(1, m // 2)])
+        want = oracle.build_probe_seq_ts(keys.astype(np.uint64), S.astype(np.uint64), table_size, shift, plen, want_table=True)
+        for variant in (0, 1, 2, 3, 4):
+            with hj.HashJoinContext(0) as c:
+                c.reserve("atomic", n2, S.size, buildVariant=variant, probeLength=plen)
+                ro, so = 4 * int(rng.integers(0, 4)), 4 * int(rng.integers(0, 4))
+                d_r = c.dev_alloc((m + 8) * 4); d_s = c.dev_alloc((S.size + 8) * 4)
+                c.copy_h2d(d_r + ro, keys); c.copy_h2d(d_s + so, S)
+                c.build_keys(d_r + ro, m, shift, table_size)
+                c.probe_keys(d_s + so, S.size)
+                c.checksums()
+                got = c.fetch()
+                tag = (block, case, n2, m, w, shift, plen, variant, got["buildVariant"], got["compactFallback"])
+                for k in ("conflicts", "totalMatches", "inputSum", "tableSumFull", "conflictSum"):
+                    assert got[k] == want[k], (k, got[k], want[k], tag)
+                assert np.array_equal(c.export_table(table_size), want["table"]), tag
+                c.dev_free(d_r); c.dev_free(d_s)
