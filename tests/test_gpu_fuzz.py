@@ -171,3 +171,35 @@ def test_key_builds_of_a_radix_shard_on_random_keys(block):
                     assert got[k] == want[k], (k, got[k], want[k], tag)
                 assert np.array_equal(c.export_table(table_size), want["table"]), tag
                 c.dev_free(d_r); c.dev_free(d_s)
+
+
+@pytest.mark.parametrize("block", range(2))
+def test_a_reused_context_on_a_random_sequence_of_relations(block):
+    """hj_build_dev with the device's pick on ONE reserved context while the relation changes at random from step to step
+    (tight, loose, no locality, duplicate-heavy, unique): only the kernels of the previously preferred variant are enqueued,
+    so every step runs on whatever the last sample left -- and must still produce the sequential table."""
+    steps = int(os.environ.get("HJ_FUZZ_CASES", "36"))
+    rng = np.random.default_rng(20264000 + block)
+    n = 1 << (16 + block)
+    S = np.arange(1, n + 1, dtype=np.uint64)
+    seen = set()
+    with hj.HashJoinContext(0) as c:
+        dR = c.dev_alloc(n * 8); dS = c.dev_alloc(n * 8)
+        c.copy_h2d(dS, S)
+        c.reserve("atomic", n, n)
+        for step in range(steps):
+            if rng.integers(0, 4) == 0:
+                R = rng.permutation(np.arange(1, n + 1, dtype=np.uint64))          # no locality at all
+            else:
+                R, _ = make_relation(rng, n)
+            R = np.ascontiguousarray(R)
+            c.copy_h2d(dR, R)
+            c.build(dR, n); c.probe(dS, n); c.checksums()
+            got = c.fetch()
+            want = oracle.build_probe_seq(R, S, 4, want_table=True)
+            seen.add(got["buildVariant"])
+            for k in ("conflicts", "totalMatches", "inputSum", "tableSumHalf", "tableSumFull", "conflictSum"):
+                assert got[k] == want[k], (block, step, k, got[k], want[k], got["buildVariant"], got["compactFallback"])
+            assert np.array_equal(c.export_table(2 * n), want["table"]), (block, step, got["buildVariant"])
+        c.dev_free(dR); c.dev_free(dS)
+    assert steps < 20 or len(seen) >= 3, seen                                      # the sequence really moved between the builds
