@@ -47,7 +47,6 @@ namespace hj {
 constexpr int kOwnThreads = 512;                 // 8 wavefronts
 constexpr int kPerThread = 8;                    // tuples per thread per tile (8-byte loads)
 constexpr int kOwnTile = kOwnThreads * kPerThread;   // 4096 tuples
-constexpr int kWaveSpan = 64 * kPerThread;       // consecutive tuples one wavefront takes per tile
 constexpr uint32_t kBlkShift = 9;
 constexpr uint32_t kBlkSlots = 1u << kBlkShift;  // 512 slots = 4 KiB
 constexpr uint32_t kWinBlocks = 16;
@@ -243,21 +242,27 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
 #endif
     };
 
-    // tile t covers chunk offsets [t*kOwnTile, ...); this thread's tuple j sits at offset
-    // t*kOwnTile + wave*kWaveSpan + 64 j + lane
-    const uint32_t tOff = wave * kWaveSpan + lane;
-    uint64_t nxt[kPerThread];
+    // Tile geometry. The bucketised table spreads the keys 4/3 as wide as the open-addressing table (four slots per three
+    // keys), so its tiles are 3/4 as long: a tile's home slots then span what an open-addressing tile's do, and the same
+    // 16-block window holds the same shuffle windows (W = 2^10: 4.8 % of the tuples deferred with tiles of 4096, the
+    // open-addressing table's 0.3 % with tiles of 3072).
+    constexpr int PER = HTM ? 6 : kPerThread;
+    constexpr int TILE = kOwnThreads * PER, SPAN = 64 * PER;
+    // tile t covers chunk offsets [t*TILE, ...); this thread's tuple j sits at offset
+    // t*TILE + wave*SPAN + 64 j + lane
+    const uint32_t tOff = wave * SPAN + lane;
+    uint64_t nxt[PER];
 #pragma unroll
-    for (int j = 0; j < kPerThread; ++j) {
+    for (int j = 0; j < PER; ++j) {
         const uint32_t o = tOff + 64 * j;
         nxt[j] = o < clen ? Rc[o] : 0;
     }
 
-    for (uint32_t tb = 0; tb < clen; tb += kOwnTile) {
+    for (uint32_t tb = 0; tb < clen; tb += TILE) {
         // ---- take the prefetched tile, start loading the next one ----
-        uint32_t klo[kPerThread], khi[kPerThread];
+        uint32_t klo[PER], khi[PER];
 #pragma unroll
-        for (int j = 0; j < kPerThread; ++j) { klo[j] = (uint32_t)nxt[j]; khi[j] = (uint32_t)(nxt[j] >> 32); }
+        for (int j = 0; j < PER; ++j) { klo[j] = (uint32_t)nxt[j]; khi[j] = (uint32_t)(nxt[j] >> 32); }
 #if HJ_OWN_PRIO
         {   // the CU's two workgroup slots take turns at the higher issue priority (hj_build_wave.hip: oldest-first
             // arbitration lets the workgroup a CU received first finish well before the second)
@@ -266,19 +271,19 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
             else __builtin_amdgcn_s_setprio(0);
         }
 #endif
-        const bool full = tb + kOwnTile <= clen;                      // wave-uniform
-        const bool firstTile = tb == 0, lastTile = tb + kOwnTile >= clen;
+        const bool full = tb + TILE <= clen;                      // wave-uniform
+        const bool firstTile = tb == 0, lastTile = tb + TILE >= clen;
         if (!lastTile) {
 #pragma unroll
-            for (int j = 0; j < kPerThread; ++j) {
-                const uint32_t o = tb + kOwnTile + tOff + 64 * j;
+            for (int j = 0; j < PER; ++j) {
+                const uint32_t o = tb + TILE + tOff + 64 * j;
                 nxt[j] = o < clen ? Rc[o] : 0;
             }
         }
         uint32_t liveMask = 0;
         uint32_t myMin = 0xFFFFFFFFu;
 #pragma unroll
-        for (int j = 0; j < kPerThread; ++j) {
+        for (int j = 0; j < PER; ++j) {
             const bool in = full | (tb + tOff + 64 * j < clen);
             const bool okKey = (khi[j] == 0) & (klo[j] != 0);
             const bool ok = in & okKey;
@@ -340,7 +345,7 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
         const bool seamTile = firstTile || lastTile;
         if (haveWin) {
 #pragma unroll
-            for (int j = 0; j < kPerThread; ++j) {
+            for (int j = 0; j < PER; ++j) {
                 const uint32_t home = home32<HTM>(klo[j], hshift, mask32);
                 const uint32_t hb = home >> kBlkShift;
                 const bool lv = (liveMask >> j) & 1u;
@@ -384,7 +389,7 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
 
         // ---- insert: fast step per 64 consecutive tuples, everything else through the retry queue ----
 #pragma unroll
-        for (int j = 0; j < kPerThread; ++j) {
+        for (int j = 0; j < PER; ++j) {
             while (qCount >= kDrainAt) retry_round();                   // keep room for one full step
             const bool lv = (liveMask >> j) & 1u;
             uint32_t mlo = klo[j];
