@@ -45,8 +45,7 @@
 namespace hj {
 
 constexpr int kOwnThreads = 512;                 // 8 wavefronts
-constexpr int kPerThread = 8;                    // tuples per thread per tile (8-byte loads)
-constexpr int kOwnTile = kOwnThreads * kPerThread;   // 4096 tuples
+constexpr int kOwnTile = 4096;                    // tuples per SAMPLE tile and the unit chunk lengths are rounded to (the build's own tiles: k_build_own, PER)
 constexpr uint32_t kBlkShift = 9;
 constexpr uint32_t kBlkSlots = 1u << kBlkShift;  // 512 slots = 4 KiB
 constexpr uint32_t kWinBlocks = 16;
@@ -242,11 +241,16 @@ k_build_own(const void* __restrict__ Rv, uint64_t n, uint64_t chunkLen,
 #endif
     };
 
-    // Tile geometry. The bucketised table spreads the keys 4/3 as wide as the open-addressing table (four slots per three
-    // keys), so its tiles are 3/4 as long: a tile's home slots then span what an open-addressing tile's do, and the same
-    // 16-block window holds the same shuffle windows (W = 2^10: 4.8 % of the tuples deferred with tiles of 4096, the
-    // open-addressing table's 0.3 % with tiles of 3072).
-    constexpr int PER = HTM ? 6 : kPerThread;
+    // Tile geometry: 3072 tuples, six per thread (round 3; 4096 before). A shorter tile's home slots span less of the 16-block
+    // window, so the window holds wider shuffle windows: at 2^27 the open-addressing build takes 549 instead of 743 us at
+    // W = 2^11 and 2.16 instead of 2.48 ms at 2^12, the same 511 us at W = 2^10 and 2 % more at 2^8 (more tiles = more window
+    // slides and barriers per tuple; tiles of 2048: +5 % there, little more gained beyond). For the bucketised table, whose
+    // keys spread 4/3 as wide (four slots per three keys), it is what makes W = 2^10 fit at all: 4.8 % of the tuples
+    // deferred with tiles of 4096, 0.25 % with 3072 (build 1.58 -> 1.03 ms).
+#ifndef HJ_OWN_PER
+#define HJ_OWN_PER 6
+#endif
+    constexpr int PER = HJ_OWN_PER;
     constexpr int TILE = kOwnThreads * PER, SPAN = 64 * PER;
     // tile t covers chunk offsets [t*TILE, ...); this thread's tuple j sits at offset
     // t*TILE + wave*SPAN + 64 j + lane
